@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — ensemble-member-timesteps/sec of the five-equation engine on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE MODEL TIMESTEP of the whole ensemble = one launch of the per-timestep HIP kernel
+(fiveeq_step_f64, include/fiveeq.h) on each GPU.  Workload (BASELINE.json configs[2], the
+largest single-GPU configuration and the one the roofline target is quoted for): 1,000,000
+members per GPU (weak scaling), CO2+CH4+N2O, fp64, deterministic RCP-like emissions
+(SURVEY.md section 8d), Latin-hypercube parameter draws (seed 20261003), state and parameters
+resident in HBM, C/T trajectory rows written every step.  Timesteps cycle through the 750-step
+scenario (t = k mod 750); the default K + W = 750 is exactly one scenario pass.
+
+Rank 0 prints ONE JSON line.  `value` = (members on all GPUs) x K / max-over-ranks wall time of
+the K timed steps.  `roofline` prices the per-step kernel against the 8 TB/s HBM peak with the
+ALGORITHMIC bytes A = w(2 SP + 4 G + 7) = 248 B per member-step; `cpu_baseline` times the CPU
+oracle (plain-C port, OpenMP) on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (param set, gases, members per GPU, description)
+    "config2": ("co2", 1, 10_000, "BASELINE configs[1]: 10k-member CO2-only ensemble, perturbed r0/rC/rT + TCR/ECS"),
+    "config3": ("multigas", 3, 1_000_000, "BASELINE configs[2]: 1M-member CO2+CH4+N2O ensemble per GPU"),
+    "config4": ("multigas", 3, 1_250_000, "BASELINE configs[3]: 10M-member multi-gas ensemble over 8 GPUs (1.25M/GPU)"),
+    "config5": ("multigas", 3, 12_500_000, "BASELINE configs[4]: 100M-member multi-gas ensemble over 8 GPUs (12.5M/GPU)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=740)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--members", type=int, default=0, help="members per GPU (default: the workload's)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--mode", default="per_step", choices=["per_step", "graph", "fused"])
+    ap.add_argument("--no-trajectory", action="store_true", help="do not store C/T rows (drops G+1 writes from A)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-members", type=int, default=100_000)
+    ap.add_argument("--kernel-samples", type=int, default=60, help="individually event-timed launches for roofline")
+    return ap.parse_args()
+
+
+def run_steps(eng, t0, k, mode):
+    """Advance k model timesteps starting at scenario index t0 (cycling); returns the next index."""
+    n = eng.n_steps
+    t = t0 % n
+    while k > 0:
+        seg = min(k, n - t)
+        eng.run(t, t + seg, mode=mode)
+        k -= seg
+        t = (t + seg) % n
+    return t
+
+
+def cpu_baseline(kind, G, n_sample, n_steps):
+    """Time the plain-C oracle (oracle/fiveeq_oracle.c, OpenMP over members) and the NumPy oracle
+    (one core) on a bounded sample of the same workload.  Baseline only."""
+    from fiveeqscm_amd import emissions, params
+    from oracle import c_oracle, fiveeq_oracle as npo
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    p = params.sample_ensemble(params.default_params(kind), n_sample)
+    E = emissions.rcp_like_emissions(n_steps, G)
+    c_oracle.run(E, p, min(n_sample, 2000), n_threads=cores, keep=())            # warm-up (page-in, threads)
+    t0 = time.perf_counter()
+    c_oracle.run(E, p, n_sample, n_threads=cores, keep=("C", "T"))
+    dt_c = time.perf_counter() - t0
+    n_np = min(n_sample, 10_000)
+    pn = dict(p)
+    for k in ("r0", "rC", "rT", "q"):
+        pn[k] = p[k][:, :n_np]
+    t0 = time.perf_counter()
+    npo.run(E, pn, n_np)
+    dt_np = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
+    except Exception:  # noqa: BLE001
+        pass
+    return {
+        "value": n_sample * n_steps / dt_c, "unit": "member-timesteps/s", "cores": cores, "kind": "port",
+        "sample": f"{n_sample} members x {n_steps} steps, {G} gas(es), fp64, oracle/fiveeq_oracle.c "
+                  f"(gcc -O2 -fopenmp, {cores} threads), {dt_c:.2f} s",
+        "cpu_model": model,
+        "numpy_1core": {"value": n_np * n_steps / dt_np, "sample": f"{n_np} members x {n_steps} steps, "
+                        f"oracle/fiveeq_oracle.py, numpy {np.__version__}, {dt_np:.2f} s"},
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit(f"--gpus {a.gpus} needs the torch.distributed.run launcher (see the docstring)")
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)        # "nccl" is RCCL on ROCm
+
+    from fiveeqscm_amd import emissions, params
+    from fiveeqscm_amd.distributed import gather_summary, shard_bounds
+    from fiveeqscm_amd.engine import EnsembleEngine
+
+    kind, G, per_gpu, desc = WORKLOADS[a.workload]
+    per_gpu = a.members or per_gpu
+    n_total = per_gpu * world
+    n_scen = 750
+    dtype = torch.float64 if a.dtype == "f64" else torch.float32
+
+    # global Latin hypercube over ALL members; this rank keeps its contiguous shard
+    lo, hi = shard_bounds(n_total, rank, world)
+    full = params.sample_ensemble(params.default_params(kind), n_total)
+    p = dict(full)
+    for k in ("r0", "rC", "rT", "q"):
+        p[k] = np.ascontiguousarray(full[k][:, lo:hi])
+    del full
+    E = emissions.rcp_like_emissions(n_scen, G)
+    eng = EnsembleEngine(p, hi - lo, E, dtype=dtype, device=dev, store_trajectory=not a.no_trajectory)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # ---- warm-up, then EXACTLY K timed steps ------------------------------------------------------
+    t_idx = run_steps(eng, 0, a.warmup, a.mode)
+    if a.mode == "graph":                      # instantiate the timed region's graphs outside the timing
+        t_probe, k = t_idx % n_scen, a.steps
+        while k > 0:
+            seg = min(k, n_scen - t_probe)
+            eng.prepare_graph(t_probe, t_probe + seg)
+            k -= seg
+            t_probe = (t_probe + seg) % n_scen
+    sync_all()
+    t0 = time.perf_counter()
+    t_idx = run_steps(eng, t_idx, a.steps, a.mode)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = n_total * a.steps / elapsed
+
+    # ---- roofline: per-launch duration of the per-step kernel, HIP events on the launch stream ----
+    # (the engine launches on torch's current stream, so torch.cuda.Event brackets exactly one kernel)
+    A = eng.bytes_per_member_step("per_step")
+    samples = []
+    for i in range(a.kernel_samples):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t = (t_idx + i) % n_scen
+        e0.record()
+        eng.step(t)
+        e1.record()
+        e1.synchronize()
+        samples.append(e0.elapsed_time(e1) * 1e-3)
+    samples = np.array(samples[5:] if len(samples) > 10 else samples)
+    k_avg = float(samples.mean())
+    achieved = A * (hi - lo) / k_avg / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            with open(tf) as fh:
+                rec = json.load(fh).get(f"{a.workload}:{a.dtype}:{per_gpu}")
+            traffic = rec["hbm_bytes_per_launch"] if rec else None
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": f"fiveeq::step_kernel<{'double' if a.dtype == 'f64' else 'float'},"
+                          f"{','.join(str(x) for x in (eng.pools + [0, 0])[:3])}>",
+                "algorithmic_bytes_per_member_step": A, "members_per_launch": hi - lo,
+                "avg_launch_us": k_avg * 1e6, "min_launch_us": float(samples.min()) * 1e6,
+                "launches_timed": int(samples.size)}
+
+    # ---- end-of-run exchange (the only collective): summary statistics of T over all members ------
+    summary = None
+    if eng.T is not None:
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter()
+        years = [t for t in (249, 499, 749) if t < n_scen]
+        summary = gather_summary(eng.T[years], percentiles=(5.0, 50.0, 95.0))
+        torch.cuda.synchronize(dev)
+        summary_ms = (time.perf_counter() - ts) * 1e3
+
+    out = {
+        "metric": "ensemble_member_timesteps_per_sec", "value": value, "unit": "member-timesteps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+        "data": "synthetic",
+        "config": {"workload": f"{a.workload}: {desc}", "members_per_gpu": per_gpu, "members_total": n_total,
+                   "gases": G, "pools": eng.pools, "scenario_steps": n_scen, "mode": a.mode,
+                   "trajectory_stored": eng.C is not None, "parallelism": f"member-shard x{world}",
+                   "emissions_sha256": emissions.emissions_sha256(E)[:16], "lhs_seed": params.LHS_SEED},
+        "roofline": roofline,
+    }
+    if summary is not None and rank == 0:
+        out["summary"] = {"years": years, "gather_ms": summary_ms,
+                          "T_mean": [float(x) for x in summary["mean"]],
+                          "T_p05_p50_p95": [[float(v) for v in row] for row in summary["percentiles"]]}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(kind, G, a.cpu_sample_members, n_scen)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""ctypes binding of the C ABI in include/fiveeq.h (libfiveeq_hip.so).
+
+There is NO fallback: if the HIP library is missing or does not export the
+expected symbols, `load()` raises.  The ensemble engine cannot run without it.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
+
+ABI_VERSION = 1
+MAX_GAS = 3
+MAX_POOLS = 4
+N_BOX = 2
+DRIVE_STRIDE = 8
+
+OK = 0
+E_INVALID = -1
+E_UNSUPPORTED = -2
+E_HIP = -3
+
+
+class FiveEqError(RuntimeError):
+    """A C-ABI call returned a negative code; `.code` holds it."""
+
+    def __init__(self, code, message):
+        super().__init__(f"fiveeq error {code}: {message}")
+        self.code = code
+
+
+class Gas(ctypes.Structure):
+    """struct fiveeq_gas (include/fiveeq.h)."""
+    _fields_ = [
+        ("a", ctypes.c_double * MAX_POOLS),
+        ("tau", ctypes.c_double * MAX_POOLS),
+        ("g0", ctypes.c_double),
+        ("g1", ctypes.c_double),
+        ("ra", ctypes.c_double),
+        ("C0", ctypes.c_double),
+        ("emis2conc", ctypes.c_double),
+        ("f", ctypes.c_double * 3),
+        ("n_pools", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class Model(ctypes.Structure):
+    """struct fiveeq_model (include/fiveeq.h)."""
+    _fields_ = [
+        ("gas", Gas * MAX_GAS),
+        ("d", ctypes.c_double * N_BOX),
+        ("iirf_max", ctypes.c_double),
+        ("dt", ctypes.c_double),
+        ("n_gas", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_mp = ctypes.POINTER(Model)
+
+# name -> (restype, argtypes); every symbol include/fiveeq.h declares
+_RUN_ARGS = [_mp, _i64, _i64, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]
+SIGNATURES = {
+    "fiveeq_abi_version": (ctypes.c_int, []),
+    "fiveeq_last_error": (ctypes.c_char_p, []),
+    "fiveeq_sizeof_model": (ctypes.c_int64, []),
+    "fiveeq_layout_supported": (ctypes.c_int, [_i32, ctypes.POINTER(_i32)]),
+    "fiveeq_step_f64": (ctypes.c_int, [_mp, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "fiveeq_step_f32": (ctypes.c_int, [_mp, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "fiveeq_run_f64": (ctypes.c_int, _RUN_ARGS),
+    "fiveeq_run_f32": (ctypes.c_int, _RUN_ARGS),
+    "fiveeq_run_fused_f64": (ctypes.c_int, _RUN_ARGS),
+    "fiveeq_run_fused_f32": (ctypes.c_int, _RUN_ARGS),
+    "fiveeq_plan_create_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.POINTER(_p)]),
+    "fiveeq_plan_create_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.POINTER(_p)]),
+    "fiveeq_plan_launch": (ctypes.c_int, [_p, _p]),
+    "fiveeq_plan_destroy": (ctypes.c_int, [_p]),
+    "fiveeq_hfc_conc_f64": (ctypes.c_int, [_i64, _i64, _i32, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """Load libfiveeq_hip.so and bind every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    lib_path = path or LIB_PATH
+    if not os.path.exists(lib_path):
+        raise ImportError(
+            f"{lib_path} not found: the HIP extension is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C fiveeqscm_amd/csrc`). "
+            "There is no CPU fallback for the ensemble engine.")
+    # torch (if present) must be imported first so that its bundled libamdhip64.so.7 is the
+    # HIP runtime this library binds to by soname: one runtime per process, so torch tensor
+    # pointers and torch streams are valid in our launches.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(lib_path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise ImportError(f"{lib_path} does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.fiveeq_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{lib_path}: ABI version {got}, expected {ABI_VERSION}")
+    if lib.fiveeq_sizeof_model() != ctypes.sizeof(Model):
+        raise ImportError(f"{lib_path}: sizeof(fiveeq_model)={lib.fiveeq_sizeof_model()} but the ctypes "
+                          f"mirror is {ctypes.sizeof(Model)} bytes")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, rc):
+    if rc != OK:
+        msg = lib.fiveeq_last_error()
+        raise FiveEqError(rc, msg.decode("utf-8", "replace") if msg else "")

@@ -1,0 +1,372 @@
+// fiveeq_capi.hip — the C ABI declared in include/fiveeq.h: host-side validation,
+// model preparation and kernel dispatch.  gfx950 only; build with
+//   hipcc --offload-arch=gfx950 -O3 -fPIC -shared -I include fiveeq_capi.hip -o libfiveeq_hip.so
+#include "fiveeq.h"
+#include "fiveeq_device.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace {
+
+using namespace fiveeq;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(FIVEEQ_E_HIP, "%s failed: %s (%d)", #expr, hipGetErrorString(e_), (int)e_); \
+    } while (0)
+
+// ---- pool layouts with a compiled kernel --------------------------------------------------
+// X(P0, P1, P2): pools of gas 0, 1, 2 (0 = gas absent).  CO2-like gases carry 4 pools,
+// single-lifetime gases (CH4, N2O, HFCs) carry 1.
+#define FIVEEQ_LAYOUTS(X) \
+    X(1, 0, 0) X(2, 0, 0) X(3, 0, 0) X(4, 0, 0) \
+    X(1, 1, 0) X(4, 1, 0) X(4, 4, 0)            \
+    X(1, 1, 1) X(4, 1, 1) X(4, 4, 1) X(4, 4, 4)
+
+int layout_code(const fiveeq_model* m) {
+    int p[3] = {0, 0, 0};
+    for (int g = 0; g < m->n_gas; ++g) p[g] = m->gas[g].n_pools;
+    return p[0] * 100 + p[1] * 10 + p[2];
+}
+
+bool layout_ok(int code) {
+    switch (code) {
+#define X(a, b, c) case (a) * 100 + (b) * 10 + (c):
+        FIVEEQ_LAYOUTS(X)
+#undef X
+        return true;
+        default:
+            return false;
+    }
+}
+
+// ---- validation (host; nothing reaches the GPU unless this passes) -------------------------
+int check_model(const fiveeq_model* m) {
+    if (!m) return fail(FIVEEQ_E_INVALID, "model is NULL");
+    if (m->n_gas < 1 || m->n_gas > FIVEEQ_MAX_GAS)
+        return fail(FIVEEQ_E_INVALID, "n_gas=%d outside 1..%d", m->n_gas, FIVEEQ_MAX_GAS);
+    if (!(m->dt > 0.0) || !std::isfinite(m->dt)) return fail(FIVEEQ_E_INVALID, "dt=%g must be finite and > 0", m->dt);
+    for (int j = 0; j < FIVEEQ_N_BOX; ++j)
+        if (!(m->d[j] > 0.0) || !std::isfinite(m->d[j]))
+            return fail(FIVEEQ_E_INVALID, "d[%d]=%g must be finite and > 0", j, m->d[j]);
+    if (std::isnan(m->iirf_max)) return fail(FIVEEQ_E_INVALID, "iirf_max is NaN");
+    for (int g = 0; g < m->n_gas; ++g) {
+        const fiveeq_gas& gs = m->gas[g];
+        if (gs.n_pools < 1 || gs.n_pools > FIVEEQ_MAX_POOLS)
+            return fail(FIVEEQ_E_INVALID, "gas %d: n_pools=%d outside 1..%d", g, gs.n_pools, FIVEEQ_MAX_POOLS);
+        for (int i = 0; i < gs.n_pools; ++i)
+            if (!(gs.tau[i] > 0.0) || !std::isfinite(gs.tau[i]) || !std::isfinite(gs.a[i]))
+                return fail(FIVEEQ_E_INVALID, "gas %d pool %d: a=%g tau=%g invalid", g, i, gs.a[i], gs.tau[i]);
+        if (!(gs.g1 != 0.0) || !std::isfinite(gs.g1) || !std::isfinite(gs.g0))
+            return fail(FIVEEQ_E_INVALID, "gas %d: g0=%g g1=%g invalid", g, gs.g0, gs.g1);
+        if (!(gs.C0 > 0.0) || !std::isfinite(gs.C0)) return fail(FIVEEQ_E_INVALID, "gas %d: C0=%g must be > 0", g, gs.C0);
+        if (!(gs.emis2conc > 0.0) || !std::isfinite(gs.emis2conc))
+            return fail(FIVEEQ_E_INVALID, "gas %d: emis2conc=%g must be > 0", g, gs.emis2conc);
+    }
+    if (!layout_ok(layout_code(m)))
+        return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", layout_code(m));
+    return FIVEEQ_OK;
+}
+
+int check_run(const fiveeq_model* m, int64_t n, int64_t ld, const void* drive, int32_t n_steps, int32_t t_begin,
+              int32_t t_end, const void* r, const void* q, const void* R, const void* S) {
+    if (int rc = check_model(m)) return rc;
+    if (n < 1) return fail(FIVEEQ_E_INVALID, "n_members=%lld must be >= 1", (long long)n);
+    if (ld < n) return fail(FIVEEQ_E_INVALID, "ld=%lld < n_members=%lld", (long long)ld, (long long)n);
+    if (n_steps < 1) return fail(FIVEEQ_E_INVALID, "n_steps=%d must be >= 1", n_steps);
+    if (t_begin < 0 || t_end > n_steps || t_begin > t_end)
+        return fail(FIVEEQ_E_INVALID, "step range [%d,%d) outside [0,%d)", t_begin, t_end, n_steps);
+    if (!drive || !r || !q || !R || !S)
+        return fail(FIVEEQ_E_INVALID, "NULL device pointer (drive=%p r=%p q=%p R=%p S=%p)", drive, r, q, R, S);
+    return FIVEEQ_OK;
+}
+
+// ---- model -> kernel-precision constants ---------------------------------------------------
+template <typename T>
+KModel<T> make_kmodel(const fiveeq_model* m) {
+    KModel<T> km;
+    std::memset(&km, 0, sizeof km);
+    for (int g = 0; g < m->n_gas; ++g) {
+        const fiveeq_gas& gs = m->gas[g];
+        KGas<T>& kg = km.gas[g];
+        for (int i = 0; i < gs.n_pools; ++i) {
+            kg.ndt_over_tau[i] = (T)(-m->dt / gs.tau[i]);
+            kg.atc[i] = (T)(gs.a[i] * gs.tau[i] * gs.emis2conc);
+        }
+        kg.g0 = (T)gs.g0;
+        kg.inv_g1 = (T)(1.0 / gs.g1);
+        kg.ra = (T)gs.ra;
+        kg.inv_c = (T)(1.0 / gs.emis2conc);
+        kg.C0 = (T)gs.C0;
+        kg.inv_C0 = (T)(1.0 / gs.C0);
+        kg.sqrtC0 = (T)std::sqrt(gs.C0);
+        kg.f1 = (T)gs.f[0];
+        kg.f2 = (T)gs.f[1];
+        kg.f3 = (T)gs.f[2];
+    }
+    for (int j = 0; j < 2; ++j) km.em1_d[j] = (T)std::expm1(-m->dt / m->d[j]);
+    km.iirf_max = (T)m->iirf_max;
+    return km;
+}
+
+// Memory-bound grid sizing: enough workgroups to fill 256 CUs x 8 resident blocks,
+// grid-stride beyond that.
+int step_grid(int64_t n) {
+    const int64_t want = (n + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK;
+    const int64_t cap = 256 * 8 * 4;
+    return (int)(want < cap ? want : cap);
+}
+
+template <typename T>
+struct RunArgs {
+    KModel<T> km;
+    int code;
+    int n_gas;
+    int64_t n, ld;
+    const T* drive;
+    const T *r, *q;
+    T *R, *S, *C_traj, *T_traj;
+};
+
+template <typename T>
+int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
+    T* C_row = a.C_traj ? a.C_traj + (int64_t)t * a.n_gas * a.ld : nullptr;
+    T* T_row = a.T_traj ? a.T_traj + (int64_t)t * a.ld : nullptr;
+    const dim3 grid(step_grid(a.n)), block(FIVEEQ_BLOCK);
+    switch (a.code) {
+#define X(p0, p1, p2)                                                                             \
+    case (p0) * 100 + (p1) * 10 + (p2):                                                           \
+        hipLaunchKernelGGL((step_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, t, a.n, \
+                           a.ld, a.r, a.q, a.R, a.S, C_row, T_row);                               \
+        break;
+        FIVEEQ_LAYOUTS(X)
+#undef X
+        default:
+            return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
+    }
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
+template <typename T>
+int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, hipStream_t st) {
+    const int64_t blocks = (a.n + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK;
+    if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one fused launch");
+    const dim3 grid((unsigned)blocks), block(FIVEEQ_BLOCK);
+    switch (a.code) {
+#define X(p0, p1, p2)                                                                               \
+    case (p0) * 100 + (p1) * 10 + (p2):                                                             \
+        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, t_begin, \
+                           t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj);               \
+        break;
+        FIVEEQ_LAYOUTS(X)
+#undef X
+        default:
+            return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
+    }
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
+template <typename T>
+int make_args(RunArgs<T>& a, const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps,
+              int32_t t_begin, int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj) {
+    if (int rc = check_run(m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S)) return rc;
+    a.km = make_kmodel<T>(m);
+    a.code = layout_code(m);
+    a.n_gas = m->n_gas;
+    a.n = n;
+    a.ld = ld;
+    a.drive = drive;
+    a.r = r;
+    a.q = q;
+    a.R = R;
+    a.S = S;
+    a.C_traj = C_traj;
+    a.T_traj = T_traj;
+    return FIVEEQ_OK;
+}
+
+template <typename T>
+int run_steps(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
+              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, void* stream) {
+    RunArgs<T> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj)) return rc;
+    for (int t = t_begin; t < t_end; ++t)
+        if (int rc = launch_step(a, t, (hipStream_t)stream)) return rc;
+    return FIVEEQ_OK;
+}
+
+template <typename T>
+int run_fused(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
+              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, void* stream) {
+    RunArgs<T> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj)) return rc;
+    if (t_begin == t_end) return FIVEEQ_OK;
+    return launch_fused(a, t_begin, t_end, (hipStream_t)stream);
+}
+
+// ---- plans: the per-step launch sequence captured into a hipGraph --------------------------
+struct Plan {
+    uint32_t magic;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+constexpr uint32_t PLAN_MAGIC = 0x35455146u;  // "FQE5"
+
+template <typename T>
+int plan_create(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
+                int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, void** plan_out) {
+    if (!plan_out) return fail(FIVEEQ_E_INVALID, "plan_out is NULL");
+    *plan_out = nullptr;
+    RunArgs<T> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj)) return rc;
+    if (t_begin == t_end) return fail(FIVEEQ_E_INVALID, "empty step range for a plan");
+    hipStream_t cap = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(cap);
+        return fail(FIVEEQ_E_HIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+    }
+    int rc = FIVEEQ_OK;
+    for (int t = t_begin; t < t_end && rc == FIVEEQ_OK; ++t) rc = launch_step(a, t, cap);
+    e = hipStreamEndCapture(cap, &graph);
+    (void)hipStreamDestroy(cap);
+    if (rc != FIVEEQ_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    if (e != hipSuccess) return fail(FIVEEQ_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return fail(FIVEEQ_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    Plan* p = new (std::nothrow) Plan{PLAN_MAGIC, graph, exec};
+    if (!p) {
+        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        return fail(FIVEEQ_E_INVALID, "out of host memory");
+    }
+    *plan_out = p;
+    return FIVEEQ_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int fiveeq_abi_version(void) { return FIVEEQ_ABI_VERSION; }
+const char* fiveeq_last_error(void) { return g_err; }
+int64_t fiveeq_sizeof_model(void) { return (int64_t)sizeof(fiveeq_model); }
+
+int fiveeq_layout_supported(int32_t n_gas, const int32_t* n_pools) {
+    if (!n_pools || n_gas < 1 || n_gas > FIVEEQ_MAX_GAS) return 0;
+    int p[3] = {0, 0, 0};
+    for (int g = 0; g < n_gas; ++g) {
+        if (n_pools[g] < 1 || n_pools[g] > FIVEEQ_MAX_POOLS) return 0;
+        p[g] = n_pools[g];
+    }
+    return layout_ok(p[0] * 100 + p[1] * 10 + p[2]) ? 1 : 0;
+}
+
+int fiveeq_step_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive, int32_t n_steps,
+                    int32_t t, const double* r, const double* q, double* R, double* S, double* C_traj,
+                    double* T_traj, void* stream) {
+    if (t < 0 || t >= n_steps) return fail(FIVEEQ_E_INVALID, "t=%d outside [0,%d)", t, n_steps);
+    return run_steps<double>(model, n_members, ld, drive, n_steps, t, t + 1, r, q, R, S, C_traj, T_traj, stream);
+}
+int fiveeq_step_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive, int32_t n_steps,
+                    int32_t t, const float* r, const float* q, float* R, float* S, float* C_traj, float* T_traj,
+                    void* stream) {
+    if (t < 0 || t >= n_steps) return fail(FIVEEQ_E_INVALID, "t=%d outside [0,%d)", t, n_steps);
+    return run_steps<float>(model, n_members, ld, drive, n_steps, t, t + 1, r, q, R, S, C_traj, T_traj, stream);
+}
+
+int fiveeq_run_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive, int32_t n_steps,
+                   int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R, double* S,
+                   double* C_traj, double* T_traj, void* stream) {
+    return run_steps<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, stream);
+}
+int fiveeq_run_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive, int32_t n_steps,
+                   int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R, float* S,
+                   float* C_traj, float* T_traj, void* stream) {
+    return run_steps<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, stream);
+}
+
+int fiveeq_run_fused_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
+                         int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q,
+                         double* R, double* S, double* C_traj, double* T_traj, void* stream) {
+    return run_fused<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, stream);
+}
+int fiveeq_run_fused_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
+                         int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
+                         float* S, float* C_traj, float* T_traj, void* stream) {
+    return run_fused<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, stream);
+}
+
+int fiveeq_plan_create_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
+                           int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q,
+                           double* R, double* S, double* C_traj, double* T_traj, void** plan_out) {
+    return plan_create<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, plan_out);
+}
+int fiveeq_plan_create_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
+                           int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
+                           float* S, float* C_traj, float* T_traj, void** plan_out) {
+    return plan_create<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, plan_out);
+}
+
+int fiveeq_plan_launch(void* plan, void* stream) {
+    Plan* p = static_cast<Plan*>(plan);
+    if (!p || p->magic != PLAN_MAGIC) return fail(FIVEEQ_E_INVALID, "not a live fiveeq plan");
+    HIP_TRY(hipGraphLaunch(p->exec, (hipStream_t)stream));
+    return FIVEEQ_OK;
+}
+
+int fiveeq_plan_destroy(void* plan) {
+    Plan* p = static_cast<Plan*>(plan);
+    if (!p || p->magic != PLAN_MAGIC) return fail(FIVEEQ_E_INVALID, "not a live fiveeq plan");
+    p->magic = 0;
+    hipError_t e1 = hipGraphExecDestroy(p->exec);
+    hipError_t e2 = hipGraphDestroy(p->graph);
+    delete p;
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(FIVEEQ_E_HIP, "graph destroy failed");
+    return FIVEEQ_OK;
+}
+
+int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time, const double* e0, const double* time,
+                        double* out, void* stream) {
+    if (n_members < 1) return fail(FIVEEQ_E_INVALID, "n_members=%lld must be >= 1", (long long)n_members);
+    if (ld < n_members) return fail(FIVEEQ_E_INVALID, "ld < n_members");
+    if (n_time < 0) return fail(FIVEEQ_E_INVALID, "n_time=%d must be >= 0", n_time);
+    if (n_time == 0) return FIVEEQ_OK;
+    if (!e0 || !time || !out) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    const int64_t blocks = (n_members + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK;
+    if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
+    hipLaunchKernelGGL(fiveeq::hfc_conc_kernel, dim3((unsigned)blocks), dim3(FIVEEQ_BLOCK), 0, (hipStream_t)stream,
+                       n_members, ld, n_time, e0, time, out);
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,298 @@
+// fiveeq_device.hpp — gfx950 device code for the five-equation FaIR ensemble step.
+//
+// Written for MI355X (CDNA4, wave64) only.  The path is element-wise over ensemble
+// members: one member per lane, struct-of-arrays rows so that a wave's 64 lanes read
+// 64 consecutive elements of each row (512 B per wave-instruction at fp64), no MFMA.
+//
+// The reference (stujen/fiveEqSCM @ v0) has no implementation of these equations
+// (only `emissions[0]*exp(-time)`, U_FaIR/concentrations.py:4-5); the function
+// split below follows the names it reserves at .coveragerc:12-19
+// (alpha_val, step_conc, step_forc, step_temp).  See include/fiveeq.h for the model.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef FIVEEQ_BLOCK
+#define FIVEEQ_BLOCK 256          // threads per workgroup (4 waves: one per SIMD)
+#endif
+#ifndef FIVEEQ_MATH_CUSTOM
+#define FIVEEQ_MATH_CUSTOM 1      // 1: hand-written range-restricted expm1 (fp64); 0: ocml
+#endif
+#ifndef FIVEEQ_NT_STORE
+#define FIVEEQ_NT_STORE 1         // trajectory rows are write-once: non-temporal stores
+#endif
+#ifndef FIVEEQ_FUSED_CHUNK
+#define FIVEEQ_FUSED_CHUNK 125    // drive-table steps staged into LDS per refill (fused kernel)
+#endif
+
+namespace fiveeq {
+
+constexpr int MAX_GAS = 3;
+constexpr int MAX_POOLS = 4;
+constexpr int DRIVE_STRIDE = 8;
+
+// ---------------------------------------------------------------------------------
+// Shared model in kernel precision, passed BY VALUE as a kernel argument: it lands in
+// the kernarg segment and is read with scalar loads into SGPRs — wave-uniform data
+// costs no VGPRs and no HBM traffic per member.
+// ---------------------------------------------------------------------------------
+template <typename T>
+struct KGas {
+    T ndt_over_tau[MAX_POOLS];  // -dt / tau_i
+    T atc[MAX_POOLS];           // a_i * tau_i * c      (so x_eq_i = atc_i * E * alpha)
+    T g0, inv_g1, ra, inv_c, C0, inv_C0, sqrtC0, f1, f2, f3;
+};
+template <typename T>
+struct KModel {
+    KGas<T> gas[MAX_GAS];
+    T em1_d[2];                 // expm1(-dt/d_j), computed on the host in fp64
+    T iirf_max;
+};
+
+template <int P0, int P1, int P2>
+struct Layout {
+    static constexpr int G = (P0 > 0) + (P1 > 0) + (P2 > 0);
+    static constexpr int SP = P0 + P1 + P2;
+    __host__ __device__ static constexpr int pools(int g) { return g == 0 ? P0 : (g == 1 ? P1 : P2); }
+    __host__ __device__ static constexpr int off(int g) { return g == 0 ? 0 : (g == 1 ? P0 : P0 + P1); }
+};
+
+// ---------------------------------------------------------------------------------
+// Math.  fp64: exp/log/sqrt from the device library (ocml, <= 1 ulp); expm1 is the hot
+// transcendental (one per pool per member-step) and its argument is always <= 0, so a
+// range-restricted version saves the general routine's extra branches:
+//   x = k ln2 + r, |r| <= ln2/2 ;  expm1(x) = 2^k (expm1 r) + (2^k - 1)
+// with expm1(r) = r + r^2 Q(r), Q the degree-12 Taylor polynomial (truncation
+// < 1.3e-17 relative on the interval).  For k = 0 the result is expm1(r) itself, so small
+// arguments (the tau ~ 1e6 yr pool: x ~ -1e-6) keep full RELATIVE accuracy.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double fe_expm1_neg(double x) {
+#if FIVEEQ_MATH_CUSTOM
+    x = fmax(x, -800.0);                                    // exp(-800) == 0: result -1
+    const double k = __builtin_rint(x * 1.4426950408889634);  // v_rndne_f64
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);   // ln2 hi (32 zero low bits)
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);          // ln2 lo
+    double q = 1.0 / 87178291200.0;                          // 1/14!
+    q = __builtin_fma(q, r, 1.0 / 6227020800.0);             // 1/13!
+    q = __builtin_fma(q, r, 1.0 / 479001600.0);              // 1/12!
+    q = __builtin_fma(q, r, 1.0 / 39916800.0);               // 1/11!
+    q = __builtin_fma(q, r, 1.0 / 3628800.0);                // 1/10!
+    q = __builtin_fma(q, r, 1.0 / 362880.0);                 // 1/9!
+    q = __builtin_fma(q, r, 1.0 / 40320.0);                  // 1/8!
+    q = __builtin_fma(q, r, 1.0 / 5040.0);                   // 1/7!
+    q = __builtin_fma(q, r, 1.0 / 720.0);                    // 1/6!
+    q = __builtin_fma(q, r, 1.0 / 120.0);                    // 1/5!
+    q = __builtin_fma(q, r, 1.0 / 24.0);                     // 1/4!
+    q = __builtin_fma(q, r, 1.0 / 6.0);                      // 1/3!
+    q = __builtin_fma(q, r, 0.5);                            // 1/2!
+    const double p = __builtin_fma(r * r, q, r);             // expm1(r)
+    const double s = __builtin_ldexp(1.0, (int)k);           // 2^k, k <= 0
+    return __builtin_fma(s, p, s - 1.0);
+#else
+    return expm1(x);
+#endif
+}
+__device__ __forceinline__ float fe_expm1_neg(float x) { return expm1f(x); }
+
+__device__ __forceinline__ double fe_exp(double x) { return exp(x); }
+__device__ __forceinline__ float fe_exp(float x) { return expf(x); }
+__device__ __forceinline__ double fe_log(double x) { return log(x); }
+__device__ __forceinline__ float fe_log(float x) { return logf(x); }
+__device__ __forceinline__ double fe_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float fe_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double fe_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float fe_min(float a, float b) { return fminf(a, b); }
+
+// ---------------------------------------------------------------------------------
+// One member, one step.  All state lives in registers; the caller moves it.
+//   drv : this step's drive record (LDS): [0..2] E_g, [3..5] cumE_g, [6] F_ext
+//   rr  : per-member r0,rC,rT per gas ;  qq: per-member q_1,q_2
+//   R,S : in/out ;  C[g], Tnew: outputs
+// Every loop has compile-time bounds and is fully unrolled: arrays stay in VGPRs.
+// ---------------------------------------------------------------------------------
+template <typename T, typename L, int g>
+__device__ __forceinline__ T gas_step(const KModel<T>& km, const T* __restrict__ drv, const T (&rr)[3 * L::G],
+                                      const T T_old, T (&R)[L::SP], T (&C)[L::G]) {
+    const KGas<T>& kg = km.gas[g];
+    constexpr int P = L::pools(g);
+    constexpr int o = L::off(g);
+    // --- alpha_val -----------------------------------------------------------------
+    T sumR = R[o];
+#pragma unroll
+    for (int i = 1; i < P; ++i) sumR += R[o + i];
+    const T G_a = sumR * kg.inv_c;
+    const T G_u = drv[3 + g] - G_a;
+    T iirf = rr[3 * g] + rr[3 * g + 1] * G_u + rr[3 * g + 2] * T_old + kg.ra * G_a;
+    iirf = fe_min(iirf, km.iirf_max);
+    const T alpha = kg.g0 * fe_exp(iirf * kg.inv_g1);
+    const T inv_alpha = T(1) / alpha;
+    const T Ea = drv[g] * alpha;
+    // --- step_conc -----------------------------------------------------------------
+    T sumN = T(0);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const T em1 = fe_expm1_neg(kg.ndt_over_tau[i] * inv_alpha);
+        const T Ri = R[o + i];
+        const T Rn = Ri + em1 * (Ri - kg.atc[i] * Ea);
+        R[o + i] = Rn;
+        sumN += Rn;
+    }
+    const T Cg = kg.C0 + sumN;
+    C[g] = Cg;
+    // --- step_forc (terms whose coefficient is zero are skipped: wave-uniform branch) ---
+    const bool pos = Cg > T(0);
+    T Fg = kg.f2 * (Cg - kg.C0);
+    if (kg.f1 != T(0)) Fg += pos ? kg.f1 * fe_log(Cg * kg.inv_C0) : T(0);
+    if (kg.f3 != T(0)) Fg += kg.f3 * ((pos ? fe_sqrt(Cg) : T(0)) - kg.sqrtC0);
+    return Fg;
+}
+
+template <typename T, typename L>
+__device__ __forceinline__ void member_step(const KModel<T>& km, const T* __restrict__ drv,
+                                            const T (&rr)[3 * L::G], const T (&qq)[2],
+                                            T (&R)[L::SP], T (&S)[2], T (&C)[L::G], T& Tnew) {
+    const T T_old = S[0] + S[1];
+    T F = drv[6];
+    F += gas_step<T, L, 0>(km, drv, rr, T_old, R, C);
+    if constexpr (L::G > 1) F += gas_step<T, L, 1>(km, drv, rr, T_old, R, C);
+    if constexpr (L::G > 2) F += gas_step<T, L, 2>(km, drv, rr, T_old, R, C);
+    // --- step_temp -------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) S[j] = S[j] + km.em1_d[j] * (S[j] - qq[j] * F);
+    Tnew = S[0] + S[1];
+}
+
+template <typename T>
+__device__ __forceinline__ void store_stream(T* p, T v) {
+#if FIVEEQ_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 1 — ONE TIMESTEP PER LAUNCH (the north-star form).
+// Per member-step HBM traffic (elements): read SP + 2 (state) + 3G + 2 (params),
+// write SP + 2 (state) + G + 1 (C, T rows)  ->  A = w (2 SP + 4 G + 7) bytes
+// (152 B CO2-only fp64, 248 B for pools 4+1+1 fp64).
+// The shared drive record of this step is staged through LDS once per workgroup.
+// Grid-stride over members; block b always touches the same members in every launch,
+// so whatever state survives in its XCD's L2 / the Infinity Cache is re-hit next step.
+// ---------------------------------------------------------------------------------
+template <typename T, int P0, int P1, int P2>
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
+    const KModel<T> km, const T* __restrict__ drive, const int t, const int64_t n, const int64_t ld,
+    const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
+    T* __restrict__ C_row /* [G][ld] of step t, or nullptr */, T* __restrict__ T_row /* [ld] or nullptr */) {
+    using L = Layout<P0, P1, P2>;
+    __shared__ T drv[DRIVE_STRIDE];
+    if (threadIdx.x < DRIVE_STRIDE) drv[threadIdx.x] = drive[(int64_t)t * DRIVE_STRIDE + threadIdx.x];
+    __syncthreads();
+
+    const int64_t stride = (int64_t)gridDim.x * FIVEEQ_BLOCK;
+    for (int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x; m < n; m += stride) {
+        T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
+#pragma unroll
+        for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + m];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + m];
+#pragma unroll
+        for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + m];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + m];
+
+        member_step<T, L>(km, drv, rr, qq, Rv, Sv, Cv, Tn);
+
+#pragma unroll
+        for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+        if (C_row != nullptr) {
+#pragma unroll
+            for (int g = 0; g < L::G; ++g) store_stream(&C_row[g * ld + m], Cv[g]);
+        }
+        if (T_row != nullptr) store_stream(&T_row[m], Tn);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 2 — TIME-FUSED: one launch advances [t_begin, t_end); a member's state and
+// parameters stay in registers for the whole span, the drive table is staged into LDS
+// FIVEEQ_FUSED_CHUNK steps at a time, and only the C/T trajectory rows go to HBM.
+// Per member-step traffic: w (G + 1) + w (2 SP + 3 G + 6) / n_steps.
+// Same member_step() as kernel 1: results are bit-identical.
+// ---------------------------------------------------------------------------------
+template <typename T, int P0, int P1, int P2>
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
+    const KModel<T> km, const T* __restrict__ drive, const int t_begin, const int t_end,
+    const int64_t n, const int64_t ld,
+    const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
+    T* __restrict__ C_traj /* [n_steps][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_steps][ld] or nullptr */) {
+    using L = Layout<P0, P1, P2>;
+    __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
+
+    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
+    const bool active = m < n;
+    const int64_t mm = active ? m : 0;    // idle tail lanes shadow member 0 and store nothing
+
+    T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
+#pragma unroll
+    for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
+
+    for (int tc = t_begin; tc < t_end; tc += FIVEEQ_FUSED_CHUNK) {
+        const int nt = min(FIVEEQ_FUSED_CHUNK, t_end - tc);
+        __syncthreads();                                  // previous chunk fully consumed
+        for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += FIVEEQ_BLOCK)
+            drv[i] = drive[(int64_t)tc * DRIVE_STRIDE + i];
+        __syncthreads();
+        for (int k = 0; k < nt; ++k) {
+            member_step<T, L>(km, &drv[k * DRIVE_STRIDE], rr, qq, Rv, Sv, Cv, Tn);
+            if (active) {
+                const int64_t t = tc + k;
+                if (C_traj != nullptr) {
+#pragma unroll
+                    for (int g = 0; g < L::G; ++g) store_stream(&C_traj[(t * L::G + g) * ld + m], Cv[g]);
+                }
+                if (T_traj != nullptr) store_stream(&T_traj[t * ld + m], Tn);
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 3 — ensemble form of the reference's calculate_hfc_conc
+// (U_FaIR/concentrations.py:5: emissions[0]*exp(-time)): out[k][m] = e0[m]*exp(-time[k]).
+// exp(-time[k]) is shared by every member: each workgroup evaluates a tile of 256 time
+// points once into LDS, then every lane scales its member by the staged factors.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void hfc_conc_kernel(
+    const int64_t n, const int64_t ld, const int n_time,
+    const double* __restrict__ e0, const double* __restrict__ time, double* __restrict__ out) {
+    __shared__ double decay[FIVEEQ_BLOCK];
+    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
+    const bool active = m < n;
+    const double e = active ? e0[m] : 0.0;
+    for (int k0 = 0; k0 < n_time; k0 += FIVEEQ_BLOCK) {
+        const int nk = min(FIVEEQ_BLOCK, n_time - k0);
+        __syncthreads();
+        if ((int)threadIdx.x < nk) decay[threadIdx.x] = exp(-time[k0 + threadIdx.x]);
+        __syncthreads();
+        if (active)
+            for (int k = 0; k < nk; ++k) store_stream(&out[(int64_t)(k0 + k) * ld + m], e * decay[k]);
+    }
+}
+
+}  // namespace fiveeq

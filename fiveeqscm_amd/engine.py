@@ -1,0 +1,193 @@
+"""Python host of the ensemble engine: torch-ROCm tensors own the memory, the C ABI
+(include/fiveeq.h) does the work.  One engine = one device = one member shard.
+
+Data layout in HBM (struct-of-arrays over members; N = members of this shard):
+    r      [3G, N]   rows g*3 + (0,1,2) = r0, rC, rT of gas g
+    q      [2,  N]   thermal-box coefficients
+    R      [SP, N]   pool contents, gas-major (SP = sum of active pools)
+    S      [2,  N]   thermal-box temperatures
+    drive  [n_steps, 8]   shared: E_g, cumulative E_g before the step, F_ext
+    C      [n_steps, G, N]   concentration trajectory   (optional)
+    T      [n_steps, N]      temperature trajectory     (optional)
+
+There is no CPU path: constructing an engine without a GPU, or without the built
+HIP library, raises.  (The reference's own function, `calculate_hfc_conc`, is a
+NumPy one-liner and lives in fiveeqscm_amd.concentrations.)
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi
+from .emissions import make_drive
+from .params import make_model, n_gas_of, pools_of
+
+_DTYPES = {torch.float64: "f64", torch.float32: "f32"}
+
+
+def _rows(x, K, N, name):
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 0:
+        x = x.reshape(1)
+    if x.ndim == 1:
+        if x.shape[0] != K:
+            raise ValueError(f"{name}: shape {x.shape}, want [{K}] or [{K},{N}]")
+        return np.broadcast_to(x[:, None], (K, N))
+    if x.shape != (K, N):
+        raise ValueError(f"{name}: shape {x.shape}, want [{K}] or [{K},{N}]")
+    return x
+
+
+class EnsembleEngine:
+    """Advance N ensemble members of the five-equation model on one MI355X."""
+
+    def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
+                 device=None, store_trajectory=True, R0=None, S0=None):
+        if dtype not in _DTYPES:
+            raise ValueError("dtype must be torch.float64 or torch.float32")
+        self.lib = _capi.load()            # raises if the HIP library is not built
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the ensemble engine has no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError(f"device {self.device}: the engine runs on a GPU only")
+        self.dtype = dtype
+        self._sfx = _DTYPES[dtype]
+        self.n_members = N = int(n_members)
+        if N < 1:
+            raise ValueError("n_members must be >= 1")
+        self.params = params
+        self.n_gas = G = n_gas_of(params)
+        self.pools = pools_of(params)
+        self.sum_pools = SP = sum(self.pools)
+        self.dt = float(dt)
+        self.model = make_model(params, dt)
+        n_pools = (ctypes.c_int32 * G)(*self.pools)
+        if not self.lib.fiveeq_layout_supported(G, n_pools):
+            raise _capi.FiveEqError(_capi.E_UNSUPPORTED, f"pool layout {self.pools} has no compiled kernel")
+
+        drive = make_drive(emissions, F_ext, dt)
+        if drive[:, G:3].any():
+            raise ValueError("emissions carry more gases than the parameter set")
+        self.n_steps = int(drive.shape[0])
+
+        dev, dt_ = self.device, dtype
+        with torch.cuda.device(dev):
+            self.drive = torch.from_numpy(drive).to(dev, dt_).contiguous()
+            rows = np.concatenate([np.stack([_rows(params[k], G, N, k)[g] for k in ("r0", "rC", "rT")])
+                                   for g in range(G)], axis=0)              # [3G, N]
+            self.r = torch.from_numpy(np.ascontiguousarray(rows)).to(dev, dt_).contiguous()
+            self.q = torch.from_numpy(np.ascontiguousarray(_rows(params["q"], 2, N, "q"))).to(dev, dt_).contiguous()
+            self.R = torch.zeros((SP, N), dtype=dt_, device=dev)
+            self.S = torch.zeros((2, N), dtype=dt_, device=dev)
+            self.C = torch.empty((self.n_steps, G, N), dtype=dt_, device=dev) if store_trajectory else None
+            self.T = torch.empty((self.n_steps, N), dtype=dt_, device=dev) if store_trajectory else None
+        self._R0 = None if R0 is None else np.asarray(R0, dtype=np.float64).reshape(SP, N)
+        self._S0 = None if S0 is None else np.asarray(S0, dtype=np.float64).reshape(2, N)
+        self.reset_state()
+        self._plans = {}
+
+    # -- state -------------------------------------------------------------------------
+    def reset_state(self):
+        """Back to the initial condition (zeros, or the R0/S0 given at construction)."""
+        if self._R0 is None:
+            self.R.zero_()
+        else:
+            self.R.copy_(torch.from_numpy(self._R0).to(self.dtype))
+        if self._S0 is None:
+            self.S.zero_()
+        else:
+            self.S.copy_(torch.from_numpy(self._S0).to(self.dtype))
+
+    # -- launches ----------------------------------------------------------------------
+    def _stream(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def _ptr(self, t):
+        return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+    def _run_args(self, t_begin, t_end):
+        N = self.n_members
+        return (ctypes.byref(self.model), N, N, self._ptr(self.drive), self.n_steps, int(t_begin), int(t_end),
+                self._ptr(self.r), self._ptr(self.q), self._ptr(self.R), self._ptr(self.S),
+                self._ptr(self.C), self._ptr(self.T))
+
+    def step(self, t, stream=None):
+        """One timestep = one kernel launch (asynchronous)."""
+        N = self.n_members
+        fn = getattr(self.lib, f"fiveeq_step_{self._sfx}")
+        with torch.cuda.device(self.device):
+            rc = fn(ctypes.byref(self.model), N, N, self._ptr(self.drive), self.n_steps, int(t),
+                    self._ptr(self.r), self._ptr(self.q), self._ptr(self.R), self._ptr(self.S),
+                    self._ptr(self.C), self._ptr(self.T), self._stream(stream))
+        _capi.check(self.lib, rc)
+
+    def run(self, t_begin=0, t_end=None, mode="per_step", stream=None):
+        """Advance steps [t_begin, t_end).  mode:
+        'per_step' one launch per timestep, enqueued from C;
+        'graph'    the same launches replayed from a captured hipGraph;
+        'fused'    one launch, state in registers across steps (bit-identical results)."""
+        t_end = self.n_steps if t_end is None else int(t_end)
+        with torch.cuda.device(self.device):
+            if mode == "per_step":
+                fn = getattr(self.lib, f"fiveeq_run_{self._sfx}")
+                rc = fn(*self._run_args(t_begin, t_end), self._stream(stream))
+            elif mode == "fused":
+                fn = getattr(self.lib, f"fiveeq_run_fused_{self._sfx}")
+                rc = fn(*self._run_args(t_begin, t_end), self._stream(stream))
+            elif mode == "graph":
+                rc = self.lib.fiveeq_plan_launch(self.prepare_graph(t_begin, t_end), self._stream(stream))
+            else:
+                raise ValueError(f"unknown mode {mode!r}")
+        _capi.check(self.lib, rc)
+
+    def prepare_graph(self, t_begin=0, t_end=None):
+        """Capture (once) the per-step launches of [t_begin, t_end) into a hipGraph plan."""
+        t_end = self.n_steps if t_end is None else int(t_end)
+        key = (int(t_begin), t_end)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = ctypes.c_void_p()
+            fn = getattr(self.lib, f"fiveeq_plan_create_{self._sfx}")
+            with torch.cuda.device(self.device):
+                _capi.check(self.lib, fn(*self._run_args(t_begin, t_end), ctypes.byref(plan)))
+            self._plans[key] = plan
+        return plan
+
+    def close(self):
+        for plan in self._plans.values():
+            self.lib.fiveeq_plan_destroy(plan)
+        self._plans = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # -- accounting ----------------------------------------------------------------------
+    def bytes_per_member_step(self, mode="per_step"):
+        """ALGORITHMIC HBM bytes per member-timestep:
+        per_step: w (2 SP + 4 G + 7)   [R,S read+write; r,q read; C,T write];
+        fused:    w (G + 1) + w (2 SP + 3 G + 6) / n_steps."""
+        w = 8 if self.dtype == torch.float64 else 4
+        G, SP = self.n_gas, self.sum_pools
+        out = (G + 1) if self.C is not None else 0
+        if mode == "fused":
+            return w * (out + (2 * SP + 3 * G + 6) / self.n_steps)
+        return w * (2 * SP + 3 * G + 6 + out)
+
+
+def run_ensemble(emissions, params, n_members, *, F_ext=None, dt=1.0, dtype=torch.float64, device=None,
+                 mode="per_step", R0=None, S0=None):
+    """Whole-series convenience wrapper: returns dict(C [n_steps,G,N], T [n_steps,N], R, S) of
+    device tensors after a synchronise."""
+    eng = EnsembleEngine(params, n_members, emissions, F_ext=F_ext, dt=dt, dtype=dtype, device=device,
+                         R0=R0, S0=S0)
+    eng.run(mode=mode)
+    torch.cuda.synchronize(eng.device)
+    out = {"C": eng.C, "T": eng.T, "R": eng.R, "S": eng.S}
+    eng.close()
+    return out

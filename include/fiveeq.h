@@ -1,0 +1,167 @@
+/*
+ * fiveeq.h — C ABI of the MI355X (gfx950) ensemble engine for the five-equation
+ * FaIR simple climate model.   Library: fiveeqscm_amd/csrc/libfiveeq_hip.so
+ *
+ * WHAT THIS REPLACES IN THE REFERENCE (stujen/fiveEqSCM @ v0)
+ *   The reference has NO native code and NO FFI: its whole
+ *   runtime is the Python function
+ *       calculate_hfc_conc(emissions, time, lifetime)   U_FaIR/concentrations.py:4-5
+ *   (duplicate: example/concentrations.py:4-5).  The five equations its README
+ *   announces (README.md:2,6,8) — pool decay R_i, iIRF->alpha, concentration C,
+ *   forcing F, two thermal boxes T_j — are not implemented there; the only trace
+ *   of the intended function split is the list of names at .coveragerc:12-19
+ *   (step_conc, step_forc, step_temp, g_1, g_0, alpha_val, k_q).  Each entry
+ *   point below cites the reference item it stands behind, or says "new".
+ *
+ * CONVENTIONS
+ *   - Plain C: pointers, sizes, one POD struct.  No torch / C++ types.
+ *   - Every `dev` pointer is DEVICE memory owned by the caller (the Python host
+ *     passes torch-ROCm tensor data_ptr()s).  The library allocates nothing on
+ *     the device, keeps no global state except the thread-local error string,
+ *     never synchronises the stream (launches are asynchronous) and is safe
+ *     to call concurrently on different streams / devices.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Return value: 0 = success; <0 = error (FIVEEQ_E_*), message retrievable
+ *     with fiveeq_last_error() on the same thread.  Arguments are validated on
+ *     the host BEFORE any launch: a bad shape never reaches the GPU.
+ *   - Struct-of-arrays over ensemble members.  A "row" is one quantity for all
+ *     members: row k of array X starts at X + k*ld; member m is element m of the
+ *     row (0 <= m < n_members <= ld).  `ld` (leading dimension, in elements)
+ *     lets a caller run a sub-range of a larger allocation.
+ *
+ * MODEL STEP (identical arithmetic in every kernel; fp64 or fp32)
+ *     T_old = S_0 + S_1
+ *     per gas g:  G_a  = (sum_i R_gi) / c_g ;   G_u = cumE_g - G_a
+ *                 iIRF = min(r0 + rC*G_u + rT*T_old + ra*G_a, iirf_max)
+ *                 alpha= g0 * exp(iIRF / g1)
+ *                 R_gi+= expm1(-dt/(alpha*tau_i)) * (R_gi - a_i*c_g*E_g*alpha*tau_i)
+ *                 C_g  = C0_g + sum_i R_gi
+ *                 F   += f1*ln(C_g/C0_g) + f2*(C_g-C0_g) + f3*(sqrt(C_g)-sqrt(C0_g))
+ *     F += F_ext ;  S_j += expm1(-dt/d_j) * (S_j - q_j*F) ;  T = S_0 + S_1
+ */
+#ifndef FIVEEQ_H
+#define FIVEEQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIVEEQ_ABI_VERSION   1
+#define FIVEEQ_MAX_GAS       3
+#define FIVEEQ_MAX_POOLS     4
+#define FIVEEQ_N_BOX         2
+#define FIVEEQ_DRIVE_STRIDE  8   /* elements per step in the drive table, below */
+
+#define FIVEEQ_OK             0
+#define FIVEEQ_E_INVALID     -1  /* bad argument (NULL pointer, size, range) */
+#define FIVEEQ_E_UNSUPPORTED -2  /* pool layout not instantiated */
+#define FIVEEQ_E_HIP         -3  /* a HIP runtime call failed */
+
+/* Shared (not per-member) parameters of one gas.  Active pools are the first
+ * n_pools entries of a[] / tau[].  g0 and g1 are the alpha-closure constants
+ * (host helpers g_0 / g_1; names from .coveragerc:15-16 of the reference). */
+typedef struct fiveeq_gas {
+    double  a[FIVEEQ_MAX_POOLS];    /* pool fractions                       */
+    double  tau[FIVEEQ_MAX_POOLS];  /* pool time-scales, years              */
+    double  g0, g1;                 /* alpha = g0 * exp(iIRF / g1)          */
+    double  ra;                     /* iIRF sensitivity to own burden G_a   */
+    double  C0;                     /* pre-industrial concentration         */
+    double  emis2conc;              /* c_g: concentration units per emission unit */
+    double  f[3];                   /* forcing coefficients: log, linear, sqrt */
+    int32_t n_pools;                /* 1..4                                  */
+    int32_t reserved;
+} fiveeq_gas;
+
+/* Whole shared model.  Always given in double; the f32 entry points round it. */
+typedef struct fiveeq_model {
+    fiveeq_gas gas[FIVEEQ_MAX_GAS];
+    double  d[FIVEEQ_N_BOX];        /* thermal-box time-scales, years       */
+    double  iirf_max;               /* clip on iIRF (e.g. 97)               */
+    double  dt;                     /* step length, years                   */
+    int32_t n_gas;                  /* 1..3                                  */
+    int32_t reserved;
+} fiveeq_model;
+
+/* Array shapes used below (G = n_gas, SP = sum of n_pools over gases):
+ *   drive  dev [n_steps][8]   shared by all members, per step:
+ *                             [0..2] E_g (emission rate), [3..5] cumulative
+ *                             emissions BEFORE the step, [6] F_ext, [7] pad
+ *   r      dev [3*G][ld]      rows g*3+0/1/2 = r0, rC, rT of gas g (per member)
+ *   q      dev [2][ld]        thermal-box coefficients (per member)
+ *   R      dev [SP][ld]       pool contents, gas-major, in/out
+ *   S      dev [2][ld]        thermal-box temperatures, in/out
+ *   C_traj dev [n_steps][G][ld]  concentrations per step (may be NULL: not stored)
+ *   T_traj dev [n_steps][ld]     temperature per step    (may be NULL: not stored)
+ */
+
+/* new — library identification */
+int         fiveeq_abi_version(void);
+const char *fiveeq_last_error(void);
+/* new — sizeof(fiveeq_model) as the library was compiled, for binding self-checks */
+int64_t     fiveeq_sizeof_model(void);
+/* new — 1 if (n_gas, n_pools[]) has a compiled kernel, else 0 */
+int         fiveeq_layout_supported(int32_t n_gas, const int32_t *n_pools);
+
+/* ONE TIMESTEP, ONE LAUNCH: the north-star hot path.  Stands where the
+ * reference intended step_conc + alpha_val + step_forc + step_temp
+ * (.coveragerc:12-14,17 — names only; no reference code exists).
+ * Reads state/params from HBM, writes state back, writes C_traj[t], T_traj[t]. */
+int fiveeq_step_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                    const double *drive, int32_t n_steps, int32_t t,
+                    const double *r, const double *q, double *R, double *S,
+                    double *C_traj, double *T_traj, void *stream);
+int fiveeq_step_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                    const float *drive, int32_t n_steps, int32_t t,
+                    const float *r, const float *q, float *R, float *S,
+                    float *C_traj, float *T_traj, void *stream);
+
+/* Steps t_begin <= t < t_end as (t_end - t_begin) launches of the kernel above,
+ * enqueued back-to-back on `stream` from C (no Python per step). */
+int fiveeq_run_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                   const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                   const double *r, const double *q, double *R, double *S,
+                   double *C_traj, double *T_traj, void *stream);
+int fiveeq_run_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                   const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                   const float *r, const float *q, float *R, float *S,
+                   float *C_traj, float *T_traj, void *stream);
+
+/* The same launch sequence captured once into a hipGraph ("plan") and replayed:
+ * removes per-launch host cost for small ensembles.  The plan bakes in the
+ * pointers; they must stay valid until fiveeq_plan_destroy. */
+int fiveeq_plan_create_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                           const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                           const double *r, const double *q, double *R, double *S,
+                           double *C_traj, double *T_traj, void **plan_out);
+int fiveeq_plan_create_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                           const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                           const float *r, const float *q, float *R, float *S,
+                           float *C_traj, float *T_traj, void **plan_out);
+int fiveeq_plan_launch(void *plan, void *stream);
+int fiveeq_plan_destroy(void *plan);
+
+/* TIME-FUSED variant: one launch advances t_begin..t_end with
+ * the member's state held in registers; only C_traj/T_traj rows are written per
+ * step.  Same arithmetic, bit-identical results to the per-step path. */
+int fiveeq_run_fused_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                         const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                         const double *r, const double *q, double *R, double *S,
+                         double *C_traj, double *T_traj, void *stream);
+int fiveeq_run_fused_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                         const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                         const float *r, const float *q, float *R, float *S,
+                         float *C_traj, float *T_traj, void *stream);
+
+/* Ensemble form of the reference's one function,
+ *   calculate_hfc_conc(emissions, time, lifetime) = emissions[0]*exp(-time)
+ * (U_FaIR/concentrations.py:4-5): out[k][m] = e0[m] * exp(-time[k]).
+ *   e0 dev [n_members], time dev [n_time], out dev [n_time][ld]. */
+int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time,
+                        const double *e0, const double *time, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIVEEQ_H */

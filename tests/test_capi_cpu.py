@@ -1,0 +1,147 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/fiveeq.h
+declares, and rejects bad arguments on the host before anything could reach a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from fiveeqscm_amd import _capi
+from fiveeqscm_amd import params as prm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    with open(os.path.join(ROOT, "include", "fiveeq.h")) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(fiveeq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _capi.load()
+    names = _header_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/fiveeq.h but not exported"
+    assert sorted(_capi.SIGNATURES) == names, "ctypes binding and header disagree"
+    assert lib.fiveeq_abi_version() == _capi.ABI_VERSION
+    assert lib.fiveeq_sizeof_model() == ctypes.sizeof(_capi.Model) == 448
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _capi.load(str(tmp_path / "libfiveeq_hip.so"))
+
+
+def test_layout_supported():
+    lib = _capi.load()
+    ok = lambda *p: lib.fiveeq_layout_supported(len(p), (ctypes.c_int32 * len(p))(*p))  # noqa: E731
+    assert ok(4) and ok(1) and ok(4, 1, 1) and ok(4, 4, 4) and ok(1, 1, 1)
+    assert not ok(2, 3) and not ok(5) and not ok(0)
+    assert lib.fiveeq_layout_supported(4, (ctypes.c_int32 * 4)(1, 1, 1, 1)) == 0
+    assert lib.fiveeq_layout_supported(1, None) == 0
+
+
+def _call_step(lib, model, n=8, ld=8, n_steps=4, t=0, ptr=0x1000):
+    p = ctypes.c_void_p(ptr)
+    return lib.fiveeq_step_f64(ctypes.byref(model), n, ld, p, n_steps, t, p, p, p, p, None, None, None)
+
+
+def test_validation_rejects_bad_arguments_before_any_launch():
+    """Every call below must return on the host with an error code: the (fake) pointers are never
+    dereferenced and no kernel is launched, so this runs without a GPU."""
+    lib = _capi.load()
+    good = prm.make_model(prm.default_params("co2"))
+    cases = [
+        (dict(n=0), "n_members"),
+        (dict(n=8, ld=4), "ld="),
+        (dict(t=4), "t=4"),
+        (dict(t=-1), "t=-1"),
+        (dict(n_steps=0), "t=0"),
+        (dict(ptr=0), "NULL device pointer"),
+    ]
+    for kw, needle in cases:
+        rc = _call_step(lib, good, **kw)
+        assert rc == _capi.E_INVALID, kw
+        assert needle in lib.fiveeq_last_error().decode(), (kw, lib.fiveeq_last_error())
+
+    def broken(edit):
+        m = prm.make_model(prm.default_params("co2"))
+        edit(m)
+        return m
+
+    bad_models = [
+        (lambda m: setattr(m, "n_gas", 0), _capi.E_INVALID),
+        (lambda m: setattr(m, "n_gas", 4), _capi.E_INVALID),
+        (lambda m: setattr(m, "dt", 0.0), _capi.E_INVALID),
+        (lambda m: setattr(m, "dt", float("nan")), _capi.E_INVALID),
+        (lambda m: m.d.__setitem__(1, -1.0), _capi.E_INVALID),
+        (lambda m: setattr(m.gas[0], "n_pools", 5), _capi.E_INVALID),
+        (lambda m: m.gas[0].tau.__setitem__(2, 0.0), _capi.E_INVALID),
+        (lambda m: setattr(m.gas[0], "g1", 0.0), _capi.E_INVALID),
+        (lambda m: setattr(m.gas[0], "C0", 0.0), _capi.E_INVALID),
+        (lambda m: setattr(m.gas[0], "emis2conc", float("inf")), _capi.E_INVALID),
+        (lambda m: (setattr(m, "n_gas", 2), setattr(m.gas[0], "n_pools", 2), setattr(m.gas[1], "n_pools", 3),
+                    setattr(m.gas[1], "g1", 1.0), setattr(m.gas[1], "C0", 1.0), setattr(m.gas[1], "emis2conc", 1.0),
+                    [m.gas[1].tau.__setitem__(i, 1.0) for i in range(3)]), _capi.E_UNSUPPORTED),
+    ]
+    for edit, want in bad_models:
+        assert _call_step(lib, broken(edit)) == want
+    assert lib.fiveeq_step_f64(None, 8, 8, None, 4, 0, None, None, None, None, None, None, None) == _capi.E_INVALID
+    with pytest.raises(_capi.FiveEqError) as ei:
+        _capi.check(lib, _call_step(lib, good, n=0))
+    assert ei.value.code == _capi.E_INVALID
+
+
+def test_run_and_plan_validation():
+    lib = _capi.load()
+    m = prm.make_model(prm.default_params("multigas"))
+    p = ctypes.c_void_p(0x1000)
+    args = lambda tb, te: (ctypes.byref(m), 8, 8, p, 10, tb, te, p, p, p, p, None, None)  # noqa: E731
+    assert lib.fiveeq_run_f64(*args(3, 2), None) == _capi.E_INVALID
+    assert lib.fiveeq_run_f32(*args(0, 11), None) == _capi.E_INVALID
+    assert lib.fiveeq_run_fused_f64(*args(-1, 2), None) == _capi.E_INVALID
+    assert lib.fiveeq_run_f64(*args(5, 5), None) == _capi.OK            # empty range: nothing launched
+    assert lib.fiveeq_run_fused_f32(*args(5, 5), None) == _capi.OK
+    assert lib.fiveeq_plan_create_f64(*args(0, 11), None) == _capi.E_INVALID
+    assert lib.fiveeq_plan_launch(None, None) == _capi.E_INVALID
+    assert lib.fiveeq_plan_destroy(None) == _capi.E_INVALID
+    assert lib.fiveeq_hfc_conc_f64(0, 0, 1, p, p, p, None) == _capi.E_INVALID
+    assert lib.fiveeq_hfc_conc_f64(4, 4, 0, None, None, None, None) == _capi.OK  # no time points: nothing to do
+    assert lib.fiveeq_hfc_conc_f64(4, 4, 3, None, p, p, None) == _capi.E_INVALID
+
+
+def test_engine_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from fiveeqscm_amd.engine import EnsembleEngine
+    from fiveeqscm_amd.emissions import rcp_like_emissions
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        EnsembleEngine(prm.default_params("co2"), 16, rcp_like_emissions(10, 1))
+
+
+def test_make_model_packs_the_parameter_dict():
+    p = prm.default_params("multigas")
+    m = prm.make_model(p, dt=0.5)
+    assert m.n_gas == 3 and m.dt == 0.5 and m.iirf_max == 97.0
+    assert [m.gas[g].n_pools for g in range(3)] == [4, 1, 1] == prm.pools_of(p)
+    assert list(m.gas[0].tau) == p["tau"][0] and m.gas[1].tau[0] == 9.15
+    assert abs(m.gas[0].g1 - 11.4137) < 1e-3 and abs(m.gas[0].g0 - 0.010184) < 1e-5
+    with pytest.raises(ValueError):
+        prm.make_model(dict(p, a=[[0.0, 1.0, 0, 0]] * 3))          # active pools must lead
+
+
+def test_latin_hypercube_is_stratified_and_seeded():
+    import numpy as np
+    u = prm.latin_hypercube(1000, 5)
+    assert u.shape == (5, 1000) and np.all((u > 0) & (u < 1))
+    for k in range(5):
+        assert np.array_equal(np.sort(np.floor(u[k] * 1000).astype(int)), np.arange(1000))
+    assert np.array_equal(u, prm.latin_hypercube(1000, 5))
+    s = prm.sample_ensemble(prm.default_params("multigas"), 5000)
+    assert np.all(s["ECS"] >= 1.1 * s["TCR"] - 1e-12) and np.all(s["q"] > 0)
+    assert s["r0"].shape == (3, 5000) and s["q"].shape == (2, 5000)
+    r0c = np.asarray(prm.default_params("multigas")["r0"])[:, None]
+    assert np.all(s["r0"] >= 0.8 * r0c - 1e-12) and np.all(s["r0"] <= 1.2 * r0c + 1e-12)

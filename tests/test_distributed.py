@@ -1,0 +1,88 @@
+"""The N>1 path on CPU: world_size-2 gloo processes exercise sharding + the end-of-run summary
+exchange (the same code that runs over RCCL on the GPUs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from fiveeqscm_amd.distributed import (gather_summary, local_moments, merge_moments, percentiles_sorted,
+                                       shard_bounds)
+
+
+def test_shard_bounds_cover_and_balance():
+    for n, w in ((10, 3), (1_000_000, 8), (7, 8), (10_000_000, 8), (5, 1)):
+        b = [shard_bounds(n, r, w) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 3, 3)
+
+
+def test_moments_merge_equals_global():
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.normal(2.0, 3.0, size=(4, 1001)))
+    parts = torch.stack([local_moments(x[:, :300]), local_moments(x[:, 300:777]), local_moments(x[:, 777:])])
+    m = merge_moments(parts)
+    np.testing.assert_allclose(m[:, 1].numpy(), x.numpy().mean(1), rtol=1e-13)
+    np.testing.assert_allclose((m[:, 2] / m[:, 0]).numpy(), x.numpy().var(1), rtol=1e-12)
+    assert torch.equal(m[:, 3], x.min(1).values) and torch.equal(m[:, 4], x.max(1).values)
+
+
+def test_percentiles_match_numpy():
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(3, 997))
+    xs = torch.sort(torch.from_numpy(x), dim=1).values
+    got = percentiles_sorted(xs, (0, 5, 50, 95, 100, 33.3)).numpy()
+    np.testing.assert_allclose(got, np.percentile(x, (0, 5, 50, 95, 100, 33.3), axis=1).T, rtol=1e-13)
+
+
+def test_single_process_summary_needs_no_process_group():
+    x = torch.arange(12, dtype=torch.float64).reshape(2, 6)
+    s = gather_summary(x, percentiles=(50.0,))
+    assert s["percentiles"][:, 0].tolist() == [2.5, 8.5] and s["count"].tolist() == [6.0, 6.0]
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(42)
+        full = rng.normal(1.5, 0.7, size=(3, n_total))            # every rank can rebuild the global T rows
+        lo, hi = shard_bounds(n_total, rank, world)
+        s = gather_summary(torch.from_numpy(full[:, lo:hi].copy()), percentiles=(5.0, 50.0, 95.0))
+        if rank == 0:
+            want = np.percentile(full, (5.0, 50.0, 95.0), axis=1).T
+            ok = (np.allclose(s["percentiles"].numpy(), want, rtol=1e-13)
+                  and np.allclose(s["mean"].numpy(), full.mean(1), rtol=1e-13)
+                  and np.allclose(s["var"].numpy(), full.var(1), rtol=1e-12)
+                  and s["count"].tolist() == [float(n_total)] * 3
+                  and np.array_equal(s["min"].numpy(), full.min(1)) and np.array_equal(s["max"].numpy(), full.max(1)))
+            q.put(bool(ok))
+        else:
+            q.put(s["percentiles"] is None and abs(float(s["mean"][0]) - full[0].mean()) < 1e-12)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [1000, 1001])        # even split and ragged split (padding path)
+def test_gloo_world2_summary_exchange(n_total):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(results)

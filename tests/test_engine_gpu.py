@@ -1,0 +1,340 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+For the five-equation path the oracle is the build's own restatement of the published
+equations — the reference (stujen/fiveEqSCM @ v0) has no implementation of it ("parity
+unpinned").  The reference's one function, emissions[0]*exp(-time)
+(U_FaIR/concentrations.py:4-5), is pinned by golden vectors generated from the reference.
+
+Tolerance (BASELINE.json north_star): fp64, <= 1e-10 relative on C and T.  T starts at 0 and
+C sits on a 278/720/270 pedestal, so the comparisons use |a-b| <= 1e-10 |b| + atol with
+atol = 1e-13 (K or ppm/ppb), far below any physical scale.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from fiveeqscm_amd import emissions as emi
+from fiveeqscm_amd import params as prm
+from oracle import c_oracle, fiveeq_oracle as npo
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+ATOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from fiveeqscm_amd import _capi
+    _capi.load()                      # the HIP library must be the thing that runs: no fallback
+    return torch.device("cuda:0")
+
+
+def _engine(params, N, E, **kw):
+    from fiveeqscm_amd.engine import EnsembleEngine
+    return EnsembleEngine(params, N, E, device="cuda:0", **kw)
+
+
+def _close(got, want, rtol=RTOL, atol=ATOL, what=""):
+    got = got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)
+    err = np.abs(got - want)
+    bound = rtol * np.abs(want) + atol
+    worst = np.max(err / bound)
+    assert np.all(np.isfinite(got)), f"{what}: non-finite output"
+    assert worst <= 1.0, f"{what}: max err/bound = {worst:.3g} (abs {err.max():.3g})"
+    return float(np.max(err / (np.abs(want) + 1e-300)))
+
+
+# ---- the reference's function, ensemble form ---------------------------------------------------
+def test_hfc_conc_kernel_matches_reference_golden(gpu, golden_hfc):
+    from fiveeqscm_amd.concentrations import calculate_hfc_conc_ensemble
+    for name in ("ref_unit_test", "config1_float_time", "fractional_time"):
+        case = next(c for c in golden_hfc["cases"] if c["name"] == name)
+        e0 = float(np.asarray(case["emissions"], dtype=np.float64).ravel()[0])
+        time = np.asarray(case["time"], dtype=np.float64).ravel()
+        want = np.array([float.fromhex(h) for h in case["out_hex"]])
+        members = np.array([e0, 2.0 * e0, 0.0, -e0, 1.0])
+        out = calculate_hfc_conc_ensemble(members, time).cpu().numpy()
+        assert out.shape == (time.size, 5)
+        # device exp vs NumPy exp: <= 1-2 ulp on normals; absolute floor for the subnormal tail
+        np.testing.assert_allclose(out[:, 0], want, rtol=1e-15, atol=1e-300, err_msg=name)
+        np.testing.assert_allclose(out[:, 1], 2.0 * want, rtol=1e-15, atol=1e-300)
+        assert np.all(out[:, 2] == 0.0)
+        np.testing.assert_array_equal(out[:, 3], -out[:, 0])
+    with pytest.raises(IndexError):
+        calculate_hfc_conc_ensemble(np.array([]), np.array([0.0, 1.0]))
+
+
+def test_hfc_conc_kernel_ragged_sizes(gpu):
+    from fiveeqscm_amd.concentrations import calculate_hfc_conc_ensemble
+    rng = np.random.default_rng(5)
+    for N, K in ((1, 1), (63, 5), (257, 300), (1000, 513)):
+        e0 = rng.normal(size=N) * 10
+        time = rng.uniform(-2, 30, size=K)
+        out = calculate_hfc_conc_ensemble(e0, time).cpu().numpy()
+        np.testing.assert_allclose(out, c_oracle.hfc_conc(e0, time), rtol=1e-15, atol=1e-300)
+
+
+def test_engine_bridge_to_reference_function(gpu, golden_hfc):
+    """One pool, a=1, tau=1, alpha=1, R(0)=E0, no emissions: the engine reproduces
+    calculate_hfc_conc at integer times: the only bridge to the reference."""
+    tau = 1.0
+    p = {"a": [[1.0, 0, 0, 0]], "tau": [[tau, 1, 1, 1]], "r0": [tau * (-np.expm1(-100.0 / tau))], "rC": [0.0],
+         "rT": [0.0], "ra": [0.0], "PI_conc": [1.0], "emis2conc": [1.0], "f": [[0.0, 0.0, 0.0]], "iirf_max": 1e9,
+         "d": [239.0, 4.1], "q": [0.33, 0.41]}
+    n_steps, N = 40, 130
+    e0 = np.linspace(0.5, 20.0, N)
+    e0[0] = 10.0
+    for mode in ("per_step", "fused"):
+        eng = _engine(p, N, np.zeros((n_steps, 1)), R0=e0[None, :])
+        eng.run(mode=mode)
+        torch.cuda.synchronize()
+        got = eng.C[:, 0, :].cpu().numpy() - 1.0
+        gold = next(c for c in golden_hfc["cases"] if c["name"] == "config1_float_time")
+        ref = np.array([float.fromhex(h) for h in gold["out_hex"]])[1:n_steps + 1]     # 10*exp(-t), t=1..40
+        np.testing.assert_allclose(got[:, 0], ref, rtol=1e-13, atol=2e-16)              # C0 = 1 pedestal: abs floor
+        np.testing.assert_allclose(got, ref[:, None] * (e0 / 10.0)[None, :], rtol=1e-13, atol=1e-15)
+
+
+# ---- five-equation parity at the BASELINE config shapes ------------------------------------------
+CASES = [
+    pytest.param("co2", 1, 10_000, 750, id="config2-co2-10k"),          # BASELINE configs[1], full size
+    pytest.param("multigas", 3, 4096 + 37, 750, id="multigas-ragged"),   # configs[2] shape, scaled, ragged tail
+    pytest.param("multigas", 3, 1, 50, id="single-member"),
+    pytest.param("co2", 1, 255, 3, id="sub-block"),
+]
+
+
+@pytest.mark.parametrize("kind,G,N,n_steps", CASES)
+def test_per_step_kernel_matches_oracle(gpu, kind, G, N, n_steps):
+    p = prm.sample_ensemble(prm.default_params(kind), N)
+    E = emi.rcp_like_emissions(n_steps, G)
+    want = npo.run(E, p, N)
+    eng = _engine(p, N, E)
+    eng.run(mode="per_step")
+    torch.cuda.synchronize()
+    _close(eng.C, want["C"], what="C")
+    _close(eng.T, want["T"], what="T")
+    _close(eng.R, np.concatenate(want["R"], axis=0), atol=1e-12, what="R")
+    _close(eng.S, want["S"], what="S")
+
+
+@pytest.mark.parametrize("kind,G,N,n_steps", CASES)
+def test_fused_and_graph_paths_are_bit_identical_to_per_step(gpu, kind, G, N, n_steps):
+    p = prm.sample_ensemble(prm.default_params(kind), N)
+    E = emi.rcp_like_emissions(n_steps, G)
+    ref = _engine(p, N, E)
+    ref.run(mode="per_step")
+    for mode in ("fused", "graph"):
+        eng = _engine(p, N, E)
+        eng.run(mode=mode)
+        torch.cuda.synchronize()
+        for name in ("C", "T", "R", "S"):
+            assert torch.equal(getattr(eng, name), getattr(ref, name)), (mode, name)
+        eng.close()
+
+
+def test_step_by_step_equals_run_and_resume(gpu):
+    """Python-driven step(t) == C-driven run(); a run split at any step resumes bit-identically
+    (checkpoint = the R,S tensors)."""
+    N, n_steps = 777, 120
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    a = _engine(p, N, E)
+    a.run()
+    b = _engine(p, N, E)
+    for t in range(n_steps):
+        b.step(t)
+    c = _engine(p, N, E)
+    c.run(0, 47, mode="fused")
+    R_ck, S_ck = c.R.clone(), c.S.clone()
+    d = _engine(p, N, E, R0=R_ck.cpu().numpy(), S0=S_ck.cpu().numpy())
+    d.run(47, n_steps, mode="per_step")
+    torch.cuda.synchronize()
+    for name in ("R", "S"):
+        assert torch.equal(getattr(a, name), getattr(b, name))
+        assert torch.equal(getattr(a, name), getattr(d, name))
+    assert torch.equal(a.C, b.C) and torch.equal(a.T, b.T)
+    assert torch.equal(a.C[47:], d.C[47:]) and torch.equal(a.T[47:], d.T[47:])
+
+
+def test_all_compiled_layouts_match_oracle(gpu):
+    rng = np.random.default_rng(11)
+    base = prm.default_params("multigas")
+    layouts = [(1,), (2,), (3,), (4,), (1, 1), (4, 1), (4, 4), (1, 1, 1), (4, 1, 1), (4, 4, 1), (4, 4, 4)]
+    N, n_steps = 300, 200
+    for pools in layouts:
+        G = len(pools)
+        a = np.zeros((G, 4))
+        tau = np.ones((G, 4))
+        for g, P in enumerate(pools):
+            w = rng.uniform(0.2, 1.0, size=P)
+            a[g, :P] = w / w.sum()
+            tau[g, :P] = np.sort(rng.uniform(2.0, 400.0, size=P))[::-1]
+        p = {"a": a, "tau": tau, "r0": [30.0, 9.0, 60.0][:G], "rC": [0.015, 0.0, 0.001][:G],
+             "rT": [3.0, -0.3, 0.5][:G], "ra": [0.0, 3e-4, 1e-4][:G], "PI_conc": base["PI_conc"][:G],
+             "emis2conc": base["emis2conc"][:G], "f": base["f"][:G], "iirf_max": 97.0, "d": base["d"],
+             "q": base["q"]}
+        p = prm.sample_ensemble(p, N, seed=3)
+        E = emi.rcp_like_emissions(n_steps, G)
+        want = npo.run(E, p, N)
+        for mode in ("per_step", "fused"):
+            eng = _engine(p, N, E)
+            eng.run(mode=mode)
+            torch.cuda.synchronize()
+            _close(eng.C, want["C"], what=f"C {pools} {mode}")
+            _close(eng.T, want["T"], what=f"T {pools} {mode}")
+
+
+def test_external_forcing_and_substeps(gpu):
+    N, n_steps, dt = 500, 300, 0.25
+    p = prm.sample_ensemble(prm.default_params("co2"), N)
+    E = emi.rcp_like_emissions(n_steps, 1)
+    F_ext = 0.5 * np.sin(np.arange(n_steps) / 11.0) - 0.2
+    want = npo.run(E, p, N, F_ext=F_ext, dt=dt)
+    eng = _engine(p, N, E, F_ext=F_ext, dt=dt)
+    eng.run()
+    torch.cuda.synchronize()
+    _close(eng.C, want["C"], what="C")
+    _close(eng.T, want["T"], what="T")
+
+
+def test_extreme_corner_of_the_hypercube(gpu):
+    """verify on the highest-emission, highest-rT corner, where alpha feeds back
+    hardest and the iIRF clip engages, not only at the centre."""
+    N = 64
+    base = prm.default_params("co2")
+    p = dict(base)
+    p["r0"] = np.full((1, N), 1.2 * base["r0"][0])
+    p["rC"] = np.full((1, N), 1.5 * base["rC"][0])
+    p["rT"] = np.linspace(0.5, 1.5, N)[None, :] * base["rT"][0]
+    p["q"] = prm.k_q(np.full(N, 2.5), np.full(N, 4.5), base["d"], prm.forcing_2x(base))
+    E = 3.0 * np.abs(emi.rcp_like_emissions(750, 1))          # ~29 GtC/yr peak, never negative
+    want = npo.run(E, p, N, keep=("C", "T", "alpha"))
+    assert want["alpha"].max() == pytest.approx(float(npo.g_0(base["a"][0], base["tau"][0]))
+                                                * np.exp(97.0 / float(npo.g_1(base["a"][0], base["tau"][0]))))
+    eng = _engine(p, N, E)
+    eng.run()
+    torch.cuda.synchronize()
+    _close(eng.C, want["C"], what="C")
+    _close(eng.T, want["T"], what="T")
+
+
+def test_no_trajectory_mode_and_negative_concentration_guard(gpu):
+    N, n_steps = 200, 100
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    E[:, 1] = -400.0                                   # drives CH4 below zero: log/sqrt guards engage
+    want = npo.run(E, p, N)
+    assert want["C"][:, 1].min() < 0
+    a = _engine(p, N, E)
+    a.run()
+    b = _engine(p, N, E, store_trajectory=False)
+    b.run()
+    c = _engine(p, N, E, store_trajectory=False)
+    c.run(mode="fused")
+    torch.cuda.synchronize()
+    _close(a.C, want["C"], what="C")
+    _close(a.T, want["T"], what="T")
+    assert b.C is None and b.T is None
+    assert torch.equal(a.R, b.R) and torch.equal(a.S, b.S) and torch.equal(a.R, c.R) and torch.equal(a.S, c.S)
+
+
+def test_fp32_kernel_tracks_fp64_oracle(gpu):
+    """BASELINE configs[4] runs fp32: stay within 2e-4 relative of the fp64 oracle over 750 steps
+    (increment-form updates keep the tau = 1e6 yr pool alive in fp32)."""
+    N = 2048
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(750, 3)
+    want = npo.run(E, p, N)
+    for mode in ("per_step", "fused"):
+        eng = _engine(p, N, E, dtype=torch.float32)
+        eng.run(mode=mode)
+        torch.cuda.synchronize()
+        _close(eng.C.double(), want["C"], rtol=2e-4, atol=1e-5, what="C32")
+        _close(eng.T.double(), want["T"], rtol=2e-4, atol=1e-5, what="T32")
+
+
+def test_sharding_invariance(gpu):
+    """Members never interact: running [0,N) as one shard or as two gives bit-identical members
+    (the property the 8-GPU partition relies on)."""
+    N, n_steps, cut = 3000, 150, 1234
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    whole = _engine(p, N, E)
+    whole.run()
+
+    def shard(lo, hi):
+        ps = dict(p)
+        for k in ("r0", "rC", "rT", "q"):
+            ps[k] = p[k][:, lo:hi]
+        e = _engine(ps, hi - lo, E)
+        e.run(mode="fused")
+        return e
+
+    s0, s1 = shard(0, cut), shard(cut, N)
+    torch.cuda.synchronize()
+    assert torch.equal(whole.C[:, :, :cut], s0.C) and torch.equal(whole.C[:, :, cut:], s1.C)
+    assert torch.equal(whole.T[:, :cut], s0.T) and torch.equal(whole.T[:, cut:], s1.T)
+
+
+def test_leading_dimension_subrange(gpu):
+    """ld > n_members: run the middle of a larger allocation through the raw C ABI and check the
+    neighbours are untouched."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    N, ld, lo, n_steps = 300, 1000, 350, 60
+    p = prm.sample_ensemble(prm.default_params("co2"), N)
+    E = emi.rcp_like_emissions(n_steps, 1)
+    ref = _engine(p, N, E)
+    ref.run()
+    dev = torch.device("cuda:0")
+    big = lambda rows: torch.full((rows, ld), -7.0, dtype=torch.float64, device=dev)   # noqa: E731
+    r, q, R, S = big(3), big(2), big(4), big(2)
+    C, T = big(n_steps), big(n_steps)
+    r[:, lo:lo + N], q[:, lo:lo + N] = ref.r, ref.q
+    R[:, lo:lo + N], S[:, lo:lo + N] = 0.0, 0.0
+    off = lambda t: ctypes.c_void_p(t.data_ptr() + lo * 8)                              # noqa: E731
+    rc = lib.fiveeq_run_f64(ctypes.byref(ref.model), N, ld, ctypes.c_void_p(ref.drive.data_ptr()), n_steps, 0,
+                            n_steps, off(r), off(q), off(R), off(S), off(C), off(T),
+                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _capi.check(lib, rc)
+    torch.cuda.synchronize()
+    assert torch.equal(C[:, lo:lo + N], ref.C[:, 0, :]) and torch.equal(T[:, lo:lo + N], ref.T)
+    assert torch.equal(R[:, lo:lo + N], ref.R)
+    for buf in (R, S, C, T):
+        assert torch.all(buf[:, :lo] == -7.0) and torch.all(buf[:, lo + N:] == -7.0)
+
+
+def test_full_size_config3_properties(gpu):
+    """BASELINE configs[2] at full size (1M members, CO2+CH4+N2O, fp64, 750 steps): the oracle cannot
+    run this in seconds, so use size-independent properties: the ensemble is a 4096-member block tiled
+    244x (+ ragged tail); every tile must equal tile 0 bit-for-bit, and tile 0 must match the oracle."""
+    N, B = 1_000_000, 4096
+    blk = prm.sample_ensemble(prm.default_params("multigas"), B)
+    p = dict(blk)
+    reps = -(-N // B)
+    for k in ("r0", "rC", "rT", "q"):
+        p[k] = np.tile(blk[k], (1, reps))[:, :N]
+    E = emi.rcp_like_emissions(750, 3)
+    eng = _engine(p, N, E)
+    eng.run()
+    torch.cuda.synchronize()
+    want = c_oracle.run(E, blk, B, n_threads=8)
+    _close(eng.C[:, :, :B], want["C"], what="C tile0")
+    _close(eng.T[:, :B], want["T"], what="T tile0")
+    full = (N // B) * B
+    Tt = eng.T[:, :full].view(750, N // B, B)
+    assert torch.equal(Tt, Tt[:, :1, :].expand_as(Tt))
+    Ct = eng.C[:, :, :full].view(750, 3, N // B, B)
+    assert torch.equal(Ct, Ct[:, :, :1, :].expand_as(Ct))
+    assert torch.equal(eng.T[:, full:], eng.T[:, :N - full])
+    # and the fused path agrees bit-for-bit at full size
+    Tp, Cp = eng.T.clone(), eng.C[-1].clone()
+    eng.reset_state()
+    eng.run(mode="fused")
+    torch.cuda.synchronize()
+    assert torch.equal(eng.T, Tp) and torch.equal(eng.C[-1], Cp)

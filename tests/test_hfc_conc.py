@@ -1,0 +1,87 @@
+"""`calculate_hfc_conc` — the one function the reference has (U_FaIR/concentrations.py:4-5).
+
+Reads like the reference's own test (tests/unit/test_hfcs.py:5-13) plus the golden vectors
+generated from the reference itself (tests/golden/make_hfc_golden.py) and the two tests the
+reference declares but never wrote (tests/unit/test_hfcs.py:15-16).
+"""
+import numpy as np
+import pytest
+
+from fiveeqscm_amd.concentrations import calculate_hfc_conc
+from oracle import fiveeq_oracle as npo
+
+IMPLS = [pytest.param(calculate_hfc_conc, id="product"), pytest.param(npo.calculate_hfc_conc, id="oracle")]
+
+
+def _inputs(case):
+    e = np.array(case["emissions"], dtype=case["emissions_dtype"]) if case["name"] != "list_emissions" \
+        else list(case["emissions"])
+    t = np.array(case["time"], dtype=case["time_dtype"])
+    if case["out_is_scalar"]:
+        t = t[()]
+    return e, t
+
+
+@pytest.mark.parametrize("fn", IMPLS)
+def test_hfc_impulse_response(fn):
+    # verbatim shape of the reference's test, tests/unit/test_hfcs.py:5-13
+    time = np.array([0, 1, 2, 3])
+    input_emissions = np.array([10, 0, 0, 0])
+    expected = 10 * np.exp(-time)
+    result = fn(input_emissions, time, lifetime=1.0)
+    np.testing.assert_allclose(result, expected)
+
+
+@pytest.mark.parametrize("fn", IMPLS)
+def test_golden_vectors_bit_exact(fn, golden_hfc):
+    """Same NumPy -> same bits as the reference produced in this container."""
+    for case in golden_hfc["cases"]:
+        e, t = _inputs(case)
+        out = fn(e, t, lifetime=case["lifetime"])
+        assert np.ndim(out) == len(case["out_shape"]), case["name"]
+        arr = np.asarray(out, dtype=np.float64)
+        assert list(arr.shape) == case["out_shape"], case["name"]
+        want = np.array([float.fromhex(h) for h in case["out_hex"]]).reshape(case["out_shape"])
+        if np.__version__ == golden_hfc["numpy"]:
+            assert arr.tobytes() == want.tobytes(), case["name"]
+        else:  # another NumPy build may round exp differently: <= 1 ulp on normals
+            np.testing.assert_allclose(arr, want, rtol=4e-16, atol=1e-320, err_msg=case["name"])
+
+
+@pytest.mark.parametrize("fn", IMPLS)
+def test_behavioural_pins(fn, golden_hfc):
+    t = np.array([0, 1, 2, 3])
+    e = np.array([10, 0, 0, 0])
+    # lifetime accepted but ignored (U_FaIR/concentrations.py:5 never reads it)
+    assert np.array_equal(fn(e, t, lifetime=1.0), fn(e, t, lifetime=123.0))
+    assert np.array_equal(fn(e, t, 1.0), fn(e, t, lifetime=1.0))          # positional works too
+    # only emissions[0] is read
+    assert np.array_equal(fn(np.array([10, 7, -3, 99]), t, lifetime=1.0), fn(e, t, lifetime=1.0))
+    # int64 in -> float64 out
+    assert fn(e, t, lifetime=1.0).dtype == np.float64
+    # empty emissions -> IndexError, as the reference
+    assert golden_hfc["empty_emissions_raises"] == "IndexError"
+    with pytest.raises(IndexError):
+        fn(np.array([]), t, lifetime=1.0)
+
+
+@pytest.mark.parametrize("fn", IMPLS)
+def test_config1_series_underflow(fn):
+    """BASELINE config 1: 750-step series; subnormals then exact zero from t = 746."""
+    e = np.zeros(750)
+    e[0] = 10
+    out = fn(e, np.arange(750), lifetime=1.0)
+    assert out.shape == (750,)
+    assert np.count_nonzero(out) == 746 and out[746] == 0.0 and out[745] > 0.0
+    assert out[744] == float.fromhex("0x0.0000000000014p-1022")
+
+
+@pytest.mark.parametrize("fn", IMPLS)
+def test_declared_but_unwritten_reference_tests(fn):
+    """tests/unit/test_hfcs.py:15-16 announce "constant emissions" and "pulse isn't in year zero".
+    Against the reference AS IT IS, both are no-ops on the output: it only reads emissions[0]."""
+    t = np.arange(5)
+    const = fn(np.full(5, 2.0), t, lifetime=1.0)           # constant emissions
+    np.testing.assert_allclose(const, 2.0 * np.exp(-t))
+    late = fn(np.array([0.0, 0.0, 10.0, 0.0, 0.0]), t, lifetime=1.0)   # pulse in year 2
+    assert np.all(late == 0.0)

@@ -1,0 +1,227 @@
+"""Known-answer / self-consistency tests of the CPU oracle for the five-equation path.
+
+The reference (stujen/fiveEqSCM @ v0) has no code, test or golden vector for this path
+("parity unpinned"); these analytic checks are what pins the oracle.
+List (i)-(vii) follows SURVEY.md section 8c.
+"""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from fiveeqscm_amd import emissions as emi
+from fiveeqscm_amd import params as prm
+from fiveeqscm_amd.concentrations import calculate_hfc_conc
+from oracle import c_oracle, fiveeq_oracle as npo
+
+CO2 = prm.default_params("co2")
+MG = prm.default_params("multigas")
+
+
+def one_pool_params(tau=1.0, alpha_one=True):
+    a = [[1.0, 0, 0, 0]]
+    t = [[tau, 1, 1, 1]]
+    r0 = tau * (-np.expm1(-100.0 / tau)) if alpha_one else 30.0      # iIRF_100 at alpha = 1
+    return {"a": a, "tau": t, "r0": [r0], "rC": [0.0], "rT": [0.0], "ra": [0.0], "PI_conc": [1.0],
+            "emis2conc": [1.0], "f": [[0.0, 0.0, 0.0]], "iirf_max": 1e9, "d": [239.0, 4.1], "q": [0.33, 0.41]}
+
+
+# (i) bridge to the reference ---------------------------------------------------------------
+@pytest.mark.parametrize("runner", [npo.run, c_oracle.run], ids=["numpy", "c"])
+def test_bridge_to_reference_function(runner, golden_hfc):
+    """One pool, a=1, tau=1, alpha forced to 1, R(0)=E0, no emissions: C(t)-C0 = E0 exp(-t),
+    i.e. `calculate_hfc_conc` at integer times (the reference models an instantaneous pulse,
+    so the bridge sets the initial condition, not the emission — SURVEY 8c (i))."""
+    p = one_pool_params()
+    n_steps = 40
+    out = runner(np.zeros((n_steps, 1)), p, 1, R0=[np.array([[10.0]])] if runner is npo.run else np.array([[10.0]]))
+    got = out["C"][:, 0, 0] - 1.0
+    t = np.arange(1, n_steps + 1)
+    want = calculate_hfc_conc(np.array([10.0]), t, lifetime=1.0)
+    np.testing.assert_allclose(got, want, rtol=4e-16 * n_steps, atol=1e-15)   # C0=1 added/subtracted: abs floor
+    gold = next(c for c in golden_hfc["cases"] if c["name"] == "ref_unit_test")
+    ref = np.array([float.fromhex(h) for h in gold["out_hex"]])
+    np.testing.assert_allclose(got[:3], ref[1:], rtol=1e-14, atol=1e-15)
+
+
+# (ii) constant alpha, constant E -> geometric sum -------------------------------------------
+def test_constant_emissions_closed_form():
+    tau, E, n = 7.5, 3.0, 60
+    p = one_pool_params(tau)
+    out = npo.run(np.full((n, 1), E), p, 1)
+    k = np.arange(1, n + 1)
+    want = E * tau * (1.0 - np.exp(-k / tau))        # R_k = E tau (1 - e^{-k/tau}), alpha = 1
+    np.testing.assert_allclose(out["C"][:, 0, 0] - 1.0, want, rtol=1e-13)
+
+
+# (iii) mass balance ---------------------------------------------------------------------------
+def test_mass_balance_bounds_slow_pool():
+    """tau = 1e4 yr at alpha = 1, non-negative emissions: the burden stays below the cumulative
+    emissions and above them less the largest possible loss, k/tau of the total, after k steps."""
+    p = one_pool_params(1e4)
+    E = np.abs(emi.rcp_like_emissions(200, 1))
+    out = npo.run(E, p, 1)
+    G_a, cum = out["C"][:, 0, 0] - 1.0, np.cumsum(E[:, 0])
+    k = np.arange(1, 201)
+    assert np.all(G_a <= cum * (1 + 1e-14))
+    assert np.all(G_a >= cum * (1.0 - k / 1e4))
+
+
+def test_cumulative_uptake_identity():
+    """G_u + G_a = sum E dt at every step (definition of the drive table's cumulative column)."""
+    E = emi.rcp_like_emissions(300, 1)
+    drive = npo.make_drive(E)
+    np.testing.assert_allclose(drive[1:, 3], np.cumsum(E[:, 0])[:-1], rtol=0, atol=0)
+    assert drive[0, 3] == 0.0
+    np.testing.assert_array_equal(drive, emi.make_drive(E))     # product host code builds the same table
+
+
+# (iv) thermal response -------------------------------------------------------------------------
+def test_step_forcing_response():
+    d = np.array([239.0, 4.1])
+    q = np.array([[0.33], [0.41]])
+    em1 = np.expm1(-1.0 / d)
+    S = np.zeros((2, 1))
+    F = np.array([3.7])
+    for k in range(1, 400):
+        S, T = npo.step_temp(S, F, q, em1)
+        want = F[0] * np.sum(q[:, 0] * (1.0 - np.exp(-k / d)))
+        assert abs(T[0] - want) < 1e-12 * want
+
+
+def test_tcr_ecs_roundtrip_through_k_q():
+    d = [239.0, 4.1]
+    F2x = 3.74
+    TCR, ECS = 1.6, 2.75
+    q = npo.k_q(TCR, ECS, d, F2x)
+    np.testing.assert_allclose(F2x * q.sum(), ECS, rtol=1e-14)
+    # 1 %/yr CO2 ramp: F(t) = F2x t/70 (log forcing); continuous response at t = 70 is TCR.
+    dt = 1.0 / 64
+    n = int(70 / dt)
+    em1 = np.expm1(-dt / np.asarray(d))
+    S = np.zeros((2, 1))
+    for k in range(n):
+        F = np.array([F2x * ((k + 0.5) * dt) / 70.0])     # mid-step forcing: 2nd-order in dt
+        S, T = npo.step_temp(S, F, q[:, None], em1)
+    assert abs(T[0] - TCR) < 2e-5
+    np.testing.assert_allclose(prm.k_q(TCR, ECS, d, F2x), q, rtol=1e-15)
+
+
+def test_equilibrium_is_ecs():
+    p = dict(CO2)
+    q = npo.k_q(1.8, 3.2, p["d"], 3.74)
+    S = np.zeros((2, 1))
+    em1 = np.expm1(-1.0 / np.asarray(p["d"]))
+    for _ in range(6000):
+        S, T = npo.step_temp(S, np.array([3.74]), q[:, None], em1)
+    assert abs(T[0] - 3.2) < 1e-9
+
+
+# (v) alpha closure ------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["co2", "multigas"])
+def test_g0_g1_reproduce_alpha_one(kind):
+    p = prm.default_params(kind)
+    a, tau = np.asarray(p["a"], float), np.asarray(p["tau"], float)
+    for g in range(a.shape[0]):
+        P = npo.n_pools_of(a[g])
+        assert abs(a[g, :P].sum() - 1.0) < 1e-12
+        g0, g1 = npo.g_0(a[g], tau[g]), npo.g_1(a[g], tau[g])
+        iirf1 = npo.iirf_exact(1.0, a[g], tau[g])
+        assert abs(g0 * np.exp(iirf1 / g1) - 1.0) < 1e-14
+        # tangency: d iIRF / d alpha at alpha = 1 equals g1
+        h = 1e-5
+        slope = (npo.iirf_exact(1 + h, a[g], tau[g]) - npo.iirf_exact(1 - h, a[g], tau[g])) / (2 * h)
+        assert abs(slope - g1) < 1e-6 * g1
+        # product host helpers agree with the oracle's
+        assert abs(prm.g_0(a[g], tau[g]) - g0) <= 4e-16 * g0
+        assert abs(prm.g_1(a[g], tau[g]) - g1) <= 4e-16 * g1
+
+
+def test_g1_small_argument_series():
+    """tau = 1e6 yr: 1-(1+x)e^-x at x = 1e-4 must not lose digits to cancellation."""
+    x = 1e-4
+    want = x**2 / 2 - x**3 / 3 + x**4 / 8 - x**5 / 30
+    assert abs(npo._h(np.array(x)) - want) < 1e-24
+    assert abs(prm._one_minus_1px_exp(x) - want) < 1e-24
+    for xx in (0.04, 0.049999, 0.05, 0.06, 1.0, 30.0):       # series/direct hand-over is continuous
+        direct = 1.0 - (1.0 + xx) * np.exp(-xx)
+        assert abs(npo._h(np.array(xx)) - direct) < 2e-16
+        assert abs(prm._one_minus_1px_exp(xx) - direct) < 2e-16
+
+
+def test_alpha_clip():
+    al = npo.alpha_val(np.array([1e6]), 0.0, 0.0, 35.0, 0.019, 4.165, 0.0, 0.01, 11.4, 97.0)
+    assert al[0] == 0.01 * np.exp(97.0 / 11.4)
+
+
+# (vi) dt-halving convergence ---------------------------------------------------------------------
+def test_dt_halving_convergence():
+    """Piecewise-constant inputs over a step make the scheme first order in dt: halving dt
+    (same emission RATE held over both half-steps) must roughly halve the distance to the
+    fine solution."""
+    E = emi.rcp_like_emissions(320, 1)
+    sols = []
+    for k in (1, 2, 4, 8):
+        Ek = np.repeat(E, k, axis=0)
+        out = npo.run(Ek, CO2, 1, dt=1.0 / k)
+        sols.append((out["C"][k - 1::k, 0, 0], out["T"][k - 1::k, 0]))
+    for var in (0, 1):
+        e1 = np.abs(sols[0][var] - sols[3][var]).max()
+        e2 = np.abs(sols[1][var] - sols[3][var]).max()
+        e4 = np.abs(sols[2][var] - sols[3][var]).max()
+        assert e2 < 0.62 * e1 and e4 < 0.62 * e2
+
+
+# physical sanity of the default sets -------------------------------------------------------------
+def test_default_run_is_physically_plausible():
+    out = npo.run(emi.rcp_like_emissions(750, 3), MG, 1)
+    C, T = out["C"][:, :, 0], out["T"][:, 0]
+    assert 400 < C[:, 0].max() < 700 and C[:, 0].argmax() > 282       # ppm, peaks after emissions peak
+    assert 1200 < C[:, 1].max() < 3000                                 # ppb CH4
+    assert 300 < C[:, 2].max() < 600                                   # ppb N2O
+    assert 1.0 < T.max() < 4.5
+    assert np.all(np.isfinite(C)) and np.all(np.isfinite(T))
+
+
+# NumPy oracle == C oracle ------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,G", [("co2", 1), ("multigas", 3)])
+def test_numpy_and_c_oracle_agree(kind, G):
+    N = 257
+    p = prm.sample_ensemble(prm.default_params(kind), N)
+    E = emi.rcp_like_emissions(750, G)
+    a = npo.run(E, p, N)
+    b = c_oracle.run(E, p, N, n_threads=2)
+    np.testing.assert_allclose(b["C"], a["C"], rtol=1e-12)
+    np.testing.assert_allclose(b["T"], a["T"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(b["R"], np.concatenate(a["R"], axis=0), rtol=1e-11, atol=1e-13)
+
+
+def test_c_oracle_hfc_conc(golden_hfc):
+    gold = next(c for c in golden_hfc["cases"] if c["name"] == "config1_float_time")
+    want = np.array([float.fromhex(h) for h in gold["out_hex"]])
+    got = c_oracle.hfc_conc([10.0, 1.0], gold["time"])
+    np.testing.assert_allclose(got[:, 0], want, rtol=4e-16, atol=1e-320)      # glibc exp vs NumPy exp: <= 1 ulp
+    np.testing.assert_allclose(got[:, 1] * 10.0, got[:, 0], rtol=4e-16, atol=1e-320)
+
+
+# (vii) property tests ------------------------------------------------------------------------------
+@settings(max_examples=40, deadline=None)
+@given(tau=st.floats(0.5, 1e7), E=st.floats(-5, 50), R=st.floats(-10, 500), alpha=st.floats(0.05, 20))
+def test_pool_update_is_exact_ode_solution(tau, E, R, alpha):
+    """R' = R e^{-dt/(alpha tau)} + a E alpha tau (1 - e^{-dt/(alpha tau)}) in increment form."""
+    a_, tau_ = np.array([1.0]), np.array([tau])
+    Rn, C = npo.step_conc(np.array([[R]]), np.array([alpha]), E, a_, tau_, 278.0, 1.0)
+    x = 1.0 / (alpha * tau)
+    want = R * np.exp(-x) + E * alpha * tau * (-np.expm1(-x))
+    assert abs(Rn[0, 0] - want) <= 1e-12 * max(1.0, abs(want), abs(R))
+    assert C[0] == 278.0 + Rn[0, 0]
+
+
+@settings(max_examples=30, deadline=None)
+@given(s=st.floats(0.1, 10.0))
+def test_linearity_in_emissions_when_alpha_is_frozen(s):
+    """rC = rT = ra = 0 freezes alpha; the pool equations are then linear: scaling E scales C - C0."""
+    p = dict(CO2, rC=[0.0], rT=[0.0])
+    E = emi.rcp_like_emissions(120, 1)
+    a = npo.run(E, p, 1)["C"][:, 0, 0] - 278.0
+    b = npo.run(s * E, p, 1)["C"][:, 0, 0] - 278.0
+    np.testing.assert_allclose(b, s * a, rtol=1e-12, atol=1e-12)
