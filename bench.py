@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--no-trajectory", action="store_true", help="do not store C/T rows (drops G+1 writes from A)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-members", type=int, default=100_000)
-    ap.add_argument("--kernel-samples", type=int, default=60, help="individually event-timed launches for roofline")
+    ap.add_argument("--kernel-batches", type=int, default=5, help="event-timed batches of 100 launches for roofline")
     return ap.parse_args()
 
 
@@ -78,7 +78,11 @@ def cpu_baseline(kind, G, n_sample, n_steps):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     p = params.sample_ensemble(params.default_params(kind), n_sample)
     E = emissions.rcp_like_emissions(n_steps, G)
-    c_oracle.run(E, p, min(n_sample, 2000), n_threads=cores, keep=())            # warm-up (page-in, threads)
+    n_warm = min(n_sample, 2000)
+    pw = dict(p)
+    for k in ("r0", "rC", "rT", "q"):
+        pw[k] = p[k][:, :n_warm]
+    c_oracle.run(E, pw, n_warm, n_threads=cores, keep=())                        # warm-up (page-in, threads)
     t0 = time.perf_counter()
     c_oracle.run(E, p, n_sample, n_threads=cores, keep=("C", "T"))
     dt_c = time.perf_counter() - t0
@@ -169,20 +173,43 @@ def main():
     value = n_total * a.steps / elapsed
 
     # ---- roofline: per-launch duration of the per-step kernel, HIP events on the launch stream ----
-    # (the engine launches on torch's current stream, so torch.cuda.Event brackets exactly one kernel)
+    # The engine launches on torch's current stream, so torch.cuda.Event (hipEvent) brackets the
+    # launches.  Each sample = one batch of `per_batch` launches enqueued back-to-back from C between
+    # two events, divided by per_batch: the queue stays full, so the quotient is the kernel's duration
+    # plus the ~1-2 us dependent-launch boundary (a single bracketed launch would add the ~10 us
+    # idle-stream launch latency instead and overstate the kernel).
     A = eng.bytes_per_member_step("per_step")
+    per_batch = 100
     samples = []
-    for i in range(a.kernel_samples):
+    for i in range(max(a.kernel_batches, 1)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t = (t_idx + i) % n_scen
+        t = (t_idx + i * per_batch) % (n_scen - per_batch)
+        eng.run(t, t + 5)                                   # keep the queue busy ahead of the first event
         e0.record()
-        eng.step(t)
+        eng.run(t + 5, t + 5 + per_batch)
         e1.record()
         e1.synchronize()
-        samples.append(e0.elapsed_time(e1) * 1e-3)
-    samples = np.array(samples[5:] if len(samples) > 10 else samples)
+        samples.append(e0.elapsed_time(e1) * 1e-3 / per_batch)
+    samples = np.array(samples)
     k_avg = float(samples.mean())
     achieved = A * (hi - lo) / k_avg / 1e9
+    # achievable copy bandwidth on this box, same access shape (8 B/lane), buffers beyond the 256 MiB L3
+    n_copy = 1 << 27                                        # 1 GiB read + 1 GiB written per launch
+    src = torch.empty(n_copy, dtype=torch.float64, device=dev).normal_()
+    dst = torch.empty_like(src)
+    import ctypes
+    cp = lambda: eng.lib.fiveeq_stream_copy_f64(n_copy, ctypes.c_void_p(src.data_ptr()),   # noqa: E731
+                                                ctypes.c_void_p(dst.data_ptr()), eng._stream())
+    for _ in range(3):
+        cp()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        cp()
+    e1.record()
+    e1.synchronize()
+    copy_gbs = 2 * n_copy * 8 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
@@ -197,8 +224,10 @@ def main():
                 "kernel": f"fiveeq::step_kernel<{'double' if a.dtype == 'f64' else 'float'},"
                           f"{','.join(str(x) for x in (eng.pools + [0, 0])[:3])}>",
                 "algorithmic_bytes_per_member_step": A, "members_per_launch": hi - lo,
+                "algorithmic_bytes_per_launch": A * (hi - lo),
                 "avg_launch_us": k_avg * 1e6, "min_launch_us": float(samples.min()) * 1e6,
-                "launches_timed": int(samples.size)}
+                "launches_timed": int(samples.size) * per_batch,
+                "stream_copy_GBs": copy_gbs, "frac_of_stream_copy": achieved / copy_gbs}
 
     # ---- end-of-run exchange (the only collective): summary statistics of T over all members ------
     summary = None

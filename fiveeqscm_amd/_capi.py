@@ -80,6 +80,7 @@ SIGNATURES = {
     "fiveeq_plan_launch": (ctypes.c_int, [_p, _p]),
     "fiveeq_plan_destroy": (ctypes.c_int, [_p]),
     "fiveeq_hfc_conc_f64": (ctypes.c_int, [_i64, _i64, _i32, _p, _p, _p, _p]),
+    "fiveeq_stream_copy_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
 }
 
 _lib = None

@@ -369,4 +369,13 @@ int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time, const dou
     return FIVEEQ_OK;
 }
 
+int fiveeq_stream_copy_f64(int64_t n, const double* src, double* dst, void* stream) {
+    if (n < 1) return fail(FIVEEQ_E_INVALID, "n=%lld must be >= 1", (long long)n);
+    if (!src || !dst) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    hipLaunchKernelGGL(fiveeq::stream_copy_kernel, dim3(step_grid(n)), dim3(FIVEEQ_BLOCK), 0, (hipStream_t)stream, n,
+                       src, dst);
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
 }  // extern "C"

@@ -295,4 +295,23 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hfc_conc_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Diagnostic — STREAM copy with the step kernel's access shape (8 B per lane), used to
+// measure achievable bandwidth and to calibrate the FETCH_SIZE / WRITE_SIZE counters.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void stream_copy_kernel(const int64_t n, const double* __restrict__ src,
+                                                                   double* __restrict__ dst) {
+    // four independent 8-byte loads in flight per lane, like the step kernel's row loads
+    const int64_t stride = (int64_t)gridDim.x * FIVEEQ_BLOCK;
+    int64_t i = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const double v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+        dst[i] = v0;
+        dst[i + stride] = v1;
+        dst[i + 2 * stride] = v2;
+        dst[i + 3 * stride] = v3;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
 }  // namespace fiveeq

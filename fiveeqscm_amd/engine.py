@@ -43,10 +43,10 @@ class EnsembleEngine:
     """Advance N ensemble members of the five-equation model on one MI355X."""
 
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
-                 device=None, store_trajectory=True, R0=None, S0=None):
+                 device=None, store_trajectory=True, R0=None, S0=None, lib_path=None):
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
-        self.lib = _capi.load()            # raises if the HIP library is not built
+        self.lib = _capi.load(lib_path)    # raises if the HIP library is not built
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the ensemble engine has no CPU fallback")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")

@@ -161,6 +161,12 @@ int fiveeq_run_fused_f32(const fiveeq_model *model, int64_t n_members, int64_t l
 int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time,
                         const double *e0, const double *time, double *out, void *stream);
 
+/* new — diagnostic: STREAM-style copy dst[i] = src[i], i < n, with the SAME access shape as the
+ * step kernel (one 8-byte element per lane, 512 B per wave-instruction, grid sized the same way).
+ * Used to measure the achievable copy bandwidth on the box and to calibrate the rocprofv3
+ * FETCH_SIZE / WRITE_SIZE counters on a known byte count (MI355X_MICROARCH.md, HBM section). */
+int fiveeq_stream_copy_f64(int64_t n, const double *src, double *dst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
