@@ -145,15 +145,33 @@ struct RunArgs {
 };
 
 template <typename T>
+constexpr int wide_mpl() { return sizeof(T) == 8 ? FIVEEQ_MPL_F64 : FIVEEQ_MPL_F32; }
+
+// Vector (MPL-wide) row accesses need every row start MPL-aligned: ld a multiple of MPL and all
+// row bases aligned to MPL*sizeof(T).  Torch allocations are; a sub-range caller may not be.
+template <typename T>
+bool rows_aligned(const RunArgs<T>& a, int mpl) {
+    const uintptr_t mask = (uintptr_t)mpl * sizeof(T) - 1;
+    auto ok = [&](const void* p) { return p == nullptr || ((uintptr_t)p & mask) == 0; };
+    return a.ld % mpl == 0 && ok(a.r) && ok(a.q) && ok(a.R) && ok(a.S) && ok(a.C_traj) && ok(a.T_traj);
+}
+
+template <typename T>
 int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
     T* C_row = a.C_traj ? a.C_traj + (int64_t)t * a.n_gas * a.ld : nullptr;
     T* T_row = a.T_traj ? a.T_traj + (int64_t)t * a.ld : nullptr;
-    const dim3 grid(step_grid(a.n)), block(FIVEEQ_BLOCK);
+    constexpr int W = wide_mpl<T>();
+    const bool wide = W > 1 && a.n >= W && rows_aligned(a, W);
+    const dim3 grid(step_grid(wide ? a.n / W : a.n)), block(FIVEEQ_BLOCK);
     switch (a.code) {
-#define X(p0, p1, p2)                                                                             \
-    case (p0) * 100 + (p1) * 10 + (p2):                                                           \
-        hipLaunchKernelGGL((step_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, t, a.n, \
-                           a.ld, a.r, a.q, a.R, a.S, C_row, T_row);                               \
+#define X(p0, p1, p2)                                                                                    \
+    case (p0) * 100 + (p1) * 10 + (p2):                                                                  \
+        if (wide)                                                                                        \
+            hipLaunchKernelGGL((step_kernel<T, p0, p1, p2, W>), grid, block, 0, st, a.km, a.drive, t, a.n, \
+                               a.ld, a.r, a.q, a.R, a.S, C_row, T_row);                                  \
+        else                                                                                             \
+            hipLaunchKernelGGL((step_kernel<T, p0, p1, p2, 1>), grid, block, 0, st, a.km, a.drive, t, a.n, \
+                               a.ld, a.r, a.q, a.R, a.S, C_row, T_row);                                  \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X

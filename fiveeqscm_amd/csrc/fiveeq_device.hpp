@@ -21,6 +21,19 @@
 #ifndef FIVEEQ_NT_STORE
 #define FIVEEQ_NT_STORE 1         // trajectory rows are write-once: non-temporal stores
 #endif
+#ifndef FIVEEQ_MODEL_LDS
+#define FIVEEQ_MODEL_LDS 1        // 1: shared model constants staged in LDS; 0: kernarg -> SGPRs
+#endif
+// Members per lane in the per-step kernel.  Measured on MI355X (profiles/r01/ab_variants.txt):
+// 16 B/lane (fp64 x2) is within +-1 % of 8 B/lane at 1M and 8M members, and fp32 x4 is 19 % SLOWER
+// at 1M (182 VGPRs -> 2 waves/SIMD).  The path is bound by HBM/Infinity-Cache throughput, not by
+// access width, so the default stays one member per lane; the wide path is kept selectable.
+#ifndef FIVEEQ_MPL_F64
+#define FIVEEQ_MPL_F64 1
+#endif
+#ifndef FIVEEQ_MPL_F32
+#define FIVEEQ_MPL_F32 1
+#endif
 #ifndef FIVEEQ_FUSED_CHUNK
 #define FIVEEQ_FUSED_CHUNK 125    // drive-table steps staged into LDS per refill (fused kernel)
 #endif
@@ -66,12 +79,8 @@ struct Layout {
 // < 1.3e-17 relative on the interval).  For k = 0 the result is expm1(r) itself, so small
 // arguments (the tau ~ 1e6 yr pool: x ~ -1e-6) keep full RELATIVE accuracy.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ double fe_expm1_neg(double x) {
-#if FIVEEQ_MATH_CUSTOM
-    x = fmax(x, -800.0);                                    // exp(-800) == 0: result -1
-    const double k = __builtin_rint(x * 1.4426950408889634);  // v_rndne_f64
-    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);   // ln2 hi (32 zero low bits)
-    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);          // ln2 lo
+// expm1(r) on |r| <= ln2/2 as r + r^2 Q(r): shared by fe_expm1_neg and fe_exp.
+__device__ __forceinline__ double fe_expm1_reduced(double r) {
     double q = 1.0 / 87178291200.0;                          // 1/14!
     q = __builtin_fma(q, r, 1.0 / 6227020800.0);             // 1/13!
     q = __builtin_fma(q, r, 1.0 / 479001600.0);              // 1/12!
@@ -85,20 +94,80 @@ __device__ __forceinline__ double fe_expm1_neg(double x) {
     q = __builtin_fma(q, r, 1.0 / 24.0);                     // 1/4!
     q = __builtin_fma(q, r, 1.0 / 6.0);                      // 1/3!
     q = __builtin_fma(q, r, 0.5);                            // 1/2!
-    const double p = __builtin_fma(r * r, q, r);             // expm1(r)
+    return __builtin_fma(r * r, q, r);
+}
+// x = k ln2 + r with |r| <= ln2/2 (two-step Cody-Waite; ln2 hi has 32 zero low bits)
+__device__ __forceinline__ double fe_reduce_ln2(double x, double& k) {
+    k = __builtin_rint(x * 1.4426950408889634);              // v_rndne_f64
+    const double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    return __builtin_fma(-k, 1.90821492927058770002e-10, r);
+}
+
+__device__ __forceinline__ double fe_expm1_neg(double x) {
+#if FIVEEQ_MATH_CUSTOM
+    x = fmax(x, -800.0);                                     // exp(-800) == 0: result -1
+    double k;
+    const double p = fe_expm1_reduced(fe_reduce_ln2(x, k));
     const double s = __builtin_ldexp(1.0, (int)k);           // 2^k, k <= 0
-    return __builtin_fma(s, p, s - 1.0);
+    return __builtin_fma(s, p, s - 1.0);                     // k = 0: exactly p
 #else
     return expm1(x);
 #endif
 }
 __device__ __forceinline__ float fe_expm1_neg(float x) { return expm1f(x); }
 
-__device__ __forceinline__ double fe_exp(double x) { return exp(x); }
-__device__ __forceinline__ float fe_exp(float x) { return expf(x); }
+// exp(x) for the alpha closure.  The argument is clamped to +-700 so that alpha is always a
+// finite normal number (e^+-700 ~ 1e+-304) and the Newton reciprocal below is always valid.
+__device__ __forceinline__ double fe_exp(double x) {
+#if FIVEEQ_MATH_CUSTOM
+    x = fmin(fmax(x, -700.0), 700.0);
+    double k;
+    const double p = fe_expm1_reduced(fe_reduce_ln2(x, k));
+    return __builtin_ldexp(1.0 + p, (int)k);
+#else
+    return exp(x);
+#endif
+}
+__device__ __forceinline__ float fe_exp(float x) { return expf(fminf(fmaxf(x, -80.0f), 80.0f)); }
+
+// 1/a for finite normal a > 0 (alpha): v_rcp_f64 seed + two Newton steps (<= 1 ulp), without the
+// scale / fixup sequence a full IEEE division needs for subnormal and infinite operands.
+__device__ __forceinline__ double fe_rcp(double a) {
+#if FIVEEQ_MATH_CUSTOM
+    double y = __builtin_amdgcn_rcp(a);
+    double e = __builtin_fma(-a, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-a, y, 1.0);
+    return __builtin_fma(y, e, y);
+#else
+    return 1.0 / a;
+#endif
+}
+__device__ __forceinline__ float fe_rcp(float a) { return 1.0f / a; }
+
 __device__ __forceinline__ double fe_log(double x) { return log(x); }
 __device__ __forceinline__ float fe_log(float x) { return logf(x); }
-__device__ __forceinline__ double fe_sqrt(double x) { return sqrt(x); }
+
+// sqrt(x) for finite normal x > 0 (a concentration): v_rsq_f64 seed, two Goldschmidt steps and a
+// final residual correction (<= 1 ulp), without the rescaling a full sqrt needs near the ends
+// of the exponent range.
+__device__ __forceinline__ double fe_sqrt(double x) {
+#if FIVEEQ_MATH_CUSTOM
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+#else
+    return sqrt(x);
+#endif
+}
 __device__ __forceinline__ float fe_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double fe_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ float fe_min(float a, float b) { return fminf(a, b); }
@@ -113,6 +182,11 @@ __device__ __forceinline__ float fe_min(float a, float b) { return fminf(a, b); 
 template <typename T, typename L, int g>
 __device__ __forceinline__ T gas_step(const KModel<T>& km, const T* __restrict__ drv, const T (&rr)[3 * L::G],
                                       const T T_old, T (&R)[L::SP], T (&C)[L::G]) {
+#if FIVEEQ_MODEL_LDS
+    // compiler-only barrier: keeps this gas's LDS constant reads inside this gas's code instead of
+    // all ~45 being hoisted to the kernel top (VGPR pressure) or out of the fused time loop
+    asm volatile("" ::: "memory");
+#endif
     const KGas<T>& kg = km.gas[g];
     constexpr int P = L::pools(g);
     constexpr int o = L::off(g);
@@ -125,7 +199,7 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const T* __restrict__
     T iirf = rr[3 * g] + rr[3 * g + 1] * G_u + rr[3 * g + 2] * T_old + kg.ra * G_a;
     iirf = fe_min(iirf, km.iirf_max);
     const T alpha = kg.g0 * fe_exp(iirf * kg.inv_g1);
-    const T inv_alpha = T(1) / alpha;
+    const T inv_alpha = fe_rcp(alpha);
     const T Ea = drv[g] * alpha;
     // --- step_conc -----------------------------------------------------------------
     T sumN = T(0);
@@ -143,7 +217,7 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const T* __restrict__
     const bool pos = Cg > T(0);
     T Fg = kg.f2 * (Cg - kg.C0);
     if (kg.f1 != T(0)) Fg += pos ? kg.f1 * fe_log(Cg * kg.inv_C0) : T(0);
-    if (kg.f3 != T(0)) Fg += kg.f3 * ((pos ? fe_sqrt(Cg) : T(0)) - kg.sqrtC0);
+    if (kg.f3 != T(0)) Fg += kg.f3 * ((pos ? fe_sqrt(pos ? Cg : T(1)) : T(0)) - kg.sqrtC0);
     return Fg;
 }
 
@@ -160,6 +234,18 @@ __device__ __forceinline__ void member_step(const KModel<T>& km, const T* __rest
 #pragma unroll
     for (int j = 0; j < 2; ++j) S[j] = S[j] + km.em1_d[j] * (S[j] - qq[j] * F);
     Tnew = S[0] + S[1];
+}
+
+// The shared model is the FIRST kernel argument (by value): its bytes sit at offset 0 of the
+// kernarg segment.  With ~45 fp64 constants per 3-gas layout plus the polynomial literals it does
+// not fit the 102-SGPR budget (118 SGPR spills -> v_readlane/v_writelane in the VALU stream), so
+// each workgroup copies it once into LDS and the lanes read it back with broadcast ds_reads,
+// which issue beside the VALU instead of in it.
+template <typename T>
+__device__ __forceinline__ void stage_model(KModel<T>* dst) {
+    constexpr int NW = sizeof(KModel<T>) / sizeof(T);
+    const T* src = (const T*)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int i = threadIdx.x; i < NW; i += FIVEEQ_BLOCK) reinterpret_cast<T*>(dst)[i] = src[i];
 }
 
 template <typename T>
@@ -180,39 +266,110 @@ __device__ __forceinline__ void store_stream(T* p, T v) {
 // Grid-stride over members; block b always touches the same members in every launch,
 // so whatever state survives in its XCD's L2 / the Infinity Cache is re-hit next step.
 // ---------------------------------------------------------------------------------
-template <typename T, int P0, int P1, int P2>
+template <typename T, int MPL>
+struct VecOf { using type = T __attribute__((ext_vector_type(MPL))); };
+template <typename T>
+struct VecOf<T, 1> { using type = T; };
+template <typename T, int MPL>
+__device__ __forceinline__ T vec_get(const typename VecOf<T, MPL>::type& v, int j) {
+    if constexpr (MPL == 1) return v; else return v[j];
+}
+template <typename T, int MPL>
+__device__ __forceinline__ void vec_set(typename VecOf<T, MPL>::type& v, int j, T x) {
+    if constexpr (MPL == 1) v = x; else v[j] = x;
+}
+
+// MPL = members per lane: each lane owns MPL CONSECUTIVE members and moves every row with one
+// MPL-wide vector access (fp64 x2 = 16 B/lane = 1 KiB per wave-instruction, the widest form).
+// The host picks MPL > 1 only when ld and every row base are MPL-aligned; the n % MPL tail
+// members are stepped by the first lanes of workgroup 0 through the scalar path.
+template <typename T, int P0, int P1, int P2, int MPL>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
     const KModel<T> km, const T* __restrict__ drive, const int t, const int64_t n, const int64_t ld,
     const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
     T* __restrict__ C_row /* [G][ld] of step t, or nullptr */, T* __restrict__ T_row /* [ld] or nullptr */) {
     using L = Layout<P0, P1, P2>;
+    using VT = typename VecOf<T, MPL>::type;
     __shared__ T drv[DRIVE_STRIDE];
+#if FIVEEQ_MODEL_LDS
+    __shared__ KModel<T> km_s;
+    stage_model(&km_s);
+    const KModel<T>& kmr = km_s;
+#else
+    const KModel<T>& kmr = km;
+#endif
     if (threadIdx.x < DRIVE_STRIDE) drv[threadIdx.x] = drive[(int64_t)t * DRIVE_STRIDE + threadIdx.x];
     __syncthreads();
 
+    const int64_t nv = n / MPL;                       // lanes' worth of full member groups
     const int64_t stride = (int64_t)gridDim.x * FIVEEQ_BLOCK;
-    for (int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x; m < n; m += stride) {
-        T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
+    for (int64_t v = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x; v < nv; v += stride) {
+        const int64_t m = v * MPL;
+        VT rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tv;
 #pragma unroll
-        for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + m];
+        for (int k = 0; k < L::SP; ++k) Rv[k] = *reinterpret_cast<const VT*>(&R[k * ld + m]);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + m];
+        for (int k = 0; k < 2; ++k) Sv[k] = *reinterpret_cast<const VT*>(&S[k * ld + m]);
 #pragma unroll
-        for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + m];
+        for (int k = 0; k < 3 * L::G; ++k) rr[k] = *reinterpret_cast<const VT*>(&r[k * ld + m]);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + m];
+        for (int k = 0; k < 2; ++k) qq[k] = *reinterpret_cast<const VT*>(&q[k * ld + m]);
 
-        member_step<T, L>(km, drv, rr, qq, Rv, Sv, Cv, Tn);
+#pragma unroll
+        for (int j = 0; j < MPL; ++j) {
+            T r1[3 * L::G], q1[2], R1[L::SP], S1[2], C1[L::G], T1;
+#pragma unroll
+            for (int k = 0; k < L::SP; ++k) R1[k] = vec_get<T, MPL>(Rv[k], j);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) S1[k] = vec_get<T, MPL>(Sv[k], j);
+#pragma unroll
+            for (int k = 0; k < 3 * L::G; ++k) r1[k] = vec_get<T, MPL>(rr[k], j);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) q1[k] = vec_get<T, MPL>(qq[k], j);
+            member_step<T, L>(kmr, drv, r1, q1, R1, S1, C1, T1);
+#pragma unroll
+            for (int k = 0; k < L::SP; ++k) vec_set<T, MPL>(Rv[k], j, R1[k]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) vec_set<T, MPL>(Sv[k], j, S1[k]);
+#pragma unroll
+            for (int g = 0; g < L::G; ++g) vec_set<T, MPL>(Cv[g], j, C1[g]);
+            vec_set<T, MPL>(Tv, j, T1);
+        }
 
 #pragma unroll
-        for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
+        for (int k = 0; k < L::SP; ++k) *reinterpret_cast<VT*>(&R[k * ld + m]) = Rv[k];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+        for (int k = 0; k < 2; ++k) *reinterpret_cast<VT*>(&S[k * ld + m]) = Sv[k];
         if (C_row != nullptr) {
 #pragma unroll
-            for (int g = 0; g < L::G; ++g) store_stream(&C_row[g * ld + m], Cv[g]);
+            for (int g = 0; g < L::G; ++g) store_stream(reinterpret_cast<VT*>(&C_row[g * ld + m]), Cv[g]);
         }
-        if (T_row != nullptr) store_stream(&T_row[m], Tn);
+        if (T_row != nullptr) store_stream(reinterpret_cast<VT*>(&T_row[m]), Tv);
+    }
+
+    if constexpr (MPL > 1) {                          // ragged tail: fewer than MPL members
+        const int64_t m = nv * MPL + threadIdx.x;
+        if (blockIdx.x == 0 && m < n) {
+            T r1[3 * L::G], q1[2], R1[L::SP], S1[2], C1[L::G], T1;
+#pragma unroll
+            for (int k = 0; k < L::SP; ++k) R1[k] = R[k * ld + m];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) S1[k] = S[k * ld + m];
+#pragma unroll
+            for (int k = 0; k < 3 * L::G; ++k) r1[k] = r[k * ld + m];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) q1[k] = q[k * ld + m];
+            member_step<T, L>(kmr, drv, r1, q1, R1, S1, C1, T1);
+#pragma unroll
+            for (int k = 0; k < L::SP; ++k) R[k * ld + m] = R1[k];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) S[k * ld + m] = S1[k];
+            if (C_row != nullptr) {
+#pragma unroll
+                for (int g = 0; g < L::G; ++g) store_stream(&C_row[g * ld + m], C1[g]);
+            }
+            if (T_row != nullptr) store_stream(&T_row[m], T1);
+        }
     }
 }
 
@@ -231,6 +388,13 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     T* __restrict__ C_traj /* [n_steps][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_steps][ld] or nullptr */) {
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
+#if FIVEEQ_MODEL_LDS
+    __shared__ KModel<T> km_s;
+    stage_model(&km_s);
+    const KModel<T>& kmr = km_s;
+#else
+    const KModel<T>& kmr = km;
+#endif
 
     const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
     const bool active = m < n;
@@ -253,7 +417,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
             drv[i] = drive[(int64_t)tc * DRIVE_STRIDE + i];
         __syncthreads();
         for (int k = 0; k < nt; ++k) {
-            member_step<T, L>(km, &drv[k * DRIVE_STRIDE], rr, qq, Rv, Sv, Cv, Tn);
+            member_step<T, L>(kmr, &drv[k * DRIVE_STRIDE], rr, qq, Rv, Sv, Cv, Tn);
             if (active) {
                 const int64_t t = tc + k;
                 if (C_traj != nullptr) {

@@ -29,10 +29,11 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--no-trajectory", action="store_true")
+    ap.add_argument("--scenario-steps", type=int, default=750, help="trajectory capacity (memory = steps*(G+1)*N*w)")
     a = ap.parse_args()
     G = 3 if a.kind == "multigas" else 1
     libs = [x for x in a.libs.split(",") if x] or [None]
-    E = emissions.rcp_like_emissions(750, G)
+    E = emissions.rcp_like_emissions(a.scenario_steps, G)
     base = params.sample_ensemble(params.default_params(a.kind), 65536)
     print(f"{'lib':28s} {'dtype':5s} {'members':>9s} {'mode':9s} {'us/step(med)':>12s} {'us/step(min)':>12s} "
           f"{'Gmember-steps/s':>15s} {'alg GB/s':>9s}")
