@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_GAS = 3
 MAX_POOLS = 4
 N_BOX = 2
@@ -63,14 +63,17 @@ _i32 = ctypes.c_int32
 _mp = ctypes.POINTER(Model)
 
 # name -> (restype, argtypes); every symbol include/fiveeq.h declares
-_RUN_ARGS = [_mp, _i64, _i64, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]
+# (model, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats, stream|plan_out)
+_RUN_ARGS = [_mp, _i64, _i64, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p]
+_STEP_ARGS = [_mp, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p]
 SIGNATURES = {
     "fiveeq_abi_version": (ctypes.c_int, []),
     "fiveeq_last_error": (ctypes.c_char_p, []),
     "fiveeq_sizeof_model": (ctypes.c_int64, []),
     "fiveeq_layout_supported": (ctypes.c_int, [_i32, ctypes.POINTER(_i32)]),
-    "fiveeq_step_f64": (ctypes.c_int, [_mp, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
-    "fiveeq_step_f32": (ctypes.c_int, [_mp, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "fiveeq_stats_waves": (ctypes.c_int64, [_i64]),
+    "fiveeq_step_f64": (ctypes.c_int, _STEP_ARGS),
+    "fiveeq_step_f32": (ctypes.c_int, _STEP_ARGS),
     "fiveeq_run_f64": (ctypes.c_int, _RUN_ARGS),
     "fiveeq_run_f32": (ctypes.c_int, _RUN_ARGS),
     "fiveeq_run_fused_f64": (ctypes.c_int, _RUN_ARGS),

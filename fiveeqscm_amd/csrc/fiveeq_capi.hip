@@ -125,13 +125,9 @@ KModel<T> make_kmodel(const fiveeq_model* m) {
     return km;
 }
 
-// Memory-bound grid sizing: enough workgroups to fill 256 CUs x 8 resident blocks,
-// grid-stride beyond that.
-int step_grid(int64_t n) {
-    const int64_t want = (n + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK;
-    const int64_t cap = 256 * 8 * 4;
-    return (int)(want < cap ? want : cap);
-}
+// One member per lane, one 256-thread workgroup per 256 members (3907 workgroups at 1M members,
+// >> 256 CUs); workgroup b owns the same members in every launch.
+int64_t member_blocks(int64_t n) { return (n + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK; }
 
 template <typename T>
 struct RunArgs {
@@ -142,36 +138,20 @@ struct RunArgs {
     const T* drive;
     const T *r, *q;
     T *R, *S, *C_traj, *T_traj;
+    int n_rows;
+    double* stats;
 };
 
 template <typename T>
-constexpr int wide_mpl() { return sizeof(T) == 8 ? FIVEEQ_MPL_F64 : FIVEEQ_MPL_F32; }
-
-// Vector (MPL-wide) row accesses need every row start MPL-aligned: ld a multiple of MPL and all
-// row bases aligned to MPL*sizeof(T).  Torch allocations are; a sub-range caller may not be.
-template <typename T>
-bool rows_aligned(const RunArgs<T>& a, int mpl) {
-    const uintptr_t mask = (uintptr_t)mpl * sizeof(T) - 1;
-    auto ok = [&](const void* p) { return p == nullptr || ((uintptr_t)p & mask) == 0; };
-    return a.ld % mpl == 0 && ok(a.r) && ok(a.q) && ok(a.R) && ok(a.S) && ok(a.C_traj) && ok(a.T_traj);
-}
-
-template <typename T>
 int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
-    T* C_row = a.C_traj ? a.C_traj + (int64_t)t * a.n_gas * a.ld : nullptr;
-    T* T_row = a.T_traj ? a.T_traj + (int64_t)t * a.ld : nullptr;
-    constexpr int W = wide_mpl<T>();
-    const bool wide = W > 1 && a.n >= W && rows_aligned(a, W);
-    const dim3 grid(step_grid(wide ? a.n / W : a.n)), block(FIVEEQ_BLOCK);
+    const int64_t blocks = member_blocks(a.n);
+    if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
+    const dim3 grid((unsigned)blocks), block(FIVEEQ_BLOCK);
     switch (a.code) {
-#define X(p0, p1, p2)                                                                                    \
-    case (p0) * 100 + (p1) * 10 + (p2):                                                                  \
-        if (wide)                                                                                        \
-            hipLaunchKernelGGL((step_kernel<T, p0, p1, p2, W>), grid, block, 0, st, a.km, a.drive, t, a.n, \
-                               a.ld, a.r, a.q, a.R, a.S, C_row, T_row);                                  \
-        else                                                                                             \
-            hipLaunchKernelGGL((step_kernel<T, p0, p1, p2, 1>), grid, block, 0, st, a.km, a.drive, t, a.n, \
-                               a.ld, a.r, a.q, a.R, a.S, C_row, T_row);                                  \
+#define X(p0, p1, p2)                                                                             \
+    case (p0) * 100 + (p1) * 10 + (p2):                                                           \
+        hipLaunchKernelGGL((step_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, t, a.n, \
+                           a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);                \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X
@@ -184,14 +164,14 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
 
 template <typename T>
 int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, hipStream_t st) {
-    const int64_t blocks = (a.n + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK;
-    if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one fused launch");
+    const int64_t blocks = member_blocks(a.n);
+    if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_BLOCK);
     switch (a.code) {
 #define X(p0, p1, p2)                                                                               \
     case (p0) * 100 + (p1) * 10 + (p2):                                                             \
         hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, t_begin, \
-                           t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj);               \
+                           t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);      \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X
@@ -204,8 +184,9 @@ int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, hipStream_t st) {
 
 template <typename T>
 int make_args(RunArgs<T>& a, const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps,
-              int32_t t_begin, int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj) {
+              int32_t t_begin, int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats) {
     if (int rc = check_run(m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S)) return rc;
+    if (n_rows < 0) return fail(FIVEEQ_E_INVALID, "n_rows=%d must be >= 0", n_rows);
     a.km = make_kmodel<T>(m);
     a.code = layout_code(m);
     a.n_gas = m->n_gas;
@@ -218,14 +199,16 @@ int make_args(RunArgs<T>& a, const fiveeq_model* m, int64_t n, int64_t ld, const
     a.S = S;
     a.C_traj = C_traj;
     a.T_traj = T_traj;
+    a.n_rows = n_rows;
+    a.stats = stats;
     return FIVEEQ_OK;
 }
 
 template <typename T>
 int run_steps(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
-              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, void* stream) {
+              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats, void* stream) {
     RunArgs<T> a;
-    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj)) return rc;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
     for (int t = t_begin; t < t_end; ++t)
         if (int rc = launch_step(a, t, (hipStream_t)stream)) return rc;
     return FIVEEQ_OK;
@@ -233,9 +216,9 @@ int run_steps(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
 
 template <typename T>
 int run_fused(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
-              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, void* stream) {
+              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats, void* stream) {
     RunArgs<T> a;
-    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj)) return rc;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
     if (t_begin == t_end) return FIVEEQ_OK;
     return launch_fused(a, t_begin, t_end, (hipStream_t)stream);
 }
@@ -250,11 +233,11 @@ constexpr uint32_t PLAN_MAGIC = 0x35455146u;  // "FQE5"
 
 template <typename T>
 int plan_create(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
-                int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, void** plan_out) {
+                int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats, void** plan_out) {
     if (!plan_out) return fail(FIVEEQ_E_INVALID, "plan_out is NULL");
     *plan_out = nullptr;
     RunArgs<T> a;
-    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj)) return rc;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
     if (t_begin == t_end) return fail(FIVEEQ_E_INVALID, "empty step range for a plan");
     hipStream_t cap = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
@@ -297,6 +280,7 @@ extern "C" {
 int fiveeq_abi_version(void) { return FIVEEQ_ABI_VERSION; }
 const char* fiveeq_last_error(void) { return g_err; }
 int64_t fiveeq_sizeof_model(void) { return (int64_t)sizeof(fiveeq_model); }
+int64_t fiveeq_stats_waves(int64_t n_members) { return n_members < 1 ? 0 : (n_members + 63) / 64; }
 
 int fiveeq_layout_supported(int32_t n_gas, const int32_t* n_pools) {
     if (!n_pools || n_gas < 1 || n_gas > FIVEEQ_MAX_GAS) return 0;
@@ -309,49 +293,52 @@ int fiveeq_layout_supported(int32_t n_gas, const int32_t* n_pools) {
 }
 
 int fiveeq_step_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive, int32_t n_steps,
-                    int32_t t, const double* r, const double* q, double* R, double* S, double* C_traj,
-                    double* T_traj, void* stream) {
+                    int32_t t, const double* r, const double* q, double* R, double* S, double* C_traj, double* T_traj,
+                    int32_t n_rows, double* T_stats, void* stream) {
     if (t < 0 || t >= n_steps) return fail(FIVEEQ_E_INVALID, "t=%d outside [0,%d)", t, n_steps);
-    return run_steps<double>(model, n_members, ld, drive, n_steps, t, t + 1, r, q, R, S, C_traj, T_traj, stream);
+    return run_steps<double>(model, n_members, ld, drive, n_steps, t, t + 1, r, q, R, S, C_traj, T_traj, n_rows, T_stats, stream);
+}
+int fiveeq_run_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive, int32_t n_steps,
+                   int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R, double* S, double* C_traj,
+                   double* T_traj, int32_t n_rows, double* T_stats, void* stream) {
+    return run_steps<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
+                        stream);
+}
+int fiveeq_run_fused_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
+                         int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
+                         double* S, double* C_traj, double* T_traj, int32_t n_rows, double* T_stats, void* stream) {
+    return run_fused<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
+                        stream);
+}
+int fiveeq_plan_create_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
+                           int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
+                           double* S, double* C_traj, double* T_traj, int32_t n_rows, double* T_stats, void** plan_out) {
+    return plan_create<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
+                          plan_out);
 }
 int fiveeq_step_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive, int32_t n_steps,
                     int32_t t, const float* r, const float* q, float* R, float* S, float* C_traj, float* T_traj,
-                    void* stream) {
+                    int32_t n_rows, double* T_stats, void* stream) {
     if (t < 0 || t >= n_steps) return fail(FIVEEQ_E_INVALID, "t=%d outside [0,%d)", t, n_steps);
-    return run_steps<float>(model, n_members, ld, drive, n_steps, t, t + 1, r, q, R, S, C_traj, T_traj, stream);
-}
-
-int fiveeq_run_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive, int32_t n_steps,
-                   int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R, double* S,
-                   double* C_traj, double* T_traj, void* stream) {
-    return run_steps<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, stream);
+    return run_steps<float>(model, n_members, ld, drive, n_steps, t, t + 1, r, q, R, S, C_traj, T_traj, n_rows, T_stats, stream);
 }
 int fiveeq_run_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive, int32_t n_steps,
-                   int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R, float* S,
-                   float* C_traj, float* T_traj, void* stream) {
-    return run_steps<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, stream);
-}
-
-int fiveeq_run_fused_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
-                         int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q,
-                         double* R, double* S, double* C_traj, double* T_traj, void* stream) {
-    return run_fused<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, stream);
+                   int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R, float* S, float* C_traj,
+                   float* T_traj, int32_t n_rows, double* T_stats, void* stream) {
+    return run_steps<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
+                        stream);
 }
 int fiveeq_run_fused_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
                          int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
-                         float* S, float* C_traj, float* T_traj, void* stream) {
-    return run_fused<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, stream);
-}
-
-int fiveeq_plan_create_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
-                           int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q,
-                           double* R, double* S, double* C_traj, double* T_traj, void** plan_out) {
-    return plan_create<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, plan_out);
+                         float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, void* stream) {
+    return run_fused<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
+                        stream);
 }
 int fiveeq_plan_create_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
                            int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
-                           float* S, float* C_traj, float* T_traj, void** plan_out) {
-    return plan_create<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, plan_out);
+                           float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, void** plan_out) {
+    return plan_create<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
+                          plan_out);
 }
 
 int fiveeq_plan_launch(void* plan, void* stream) {
@@ -390,8 +377,8 @@ int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time, const dou
 int fiveeq_stream_copy_f64(int64_t n, const double* src, double* dst, void* stream) {
     if (n < 1) return fail(FIVEEQ_E_INVALID, "n=%lld must be >= 1", (long long)n);
     if (!src || !dst) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
-    hipLaunchKernelGGL(fiveeq::stream_copy_kernel, dim3(step_grid(n)), dim3(FIVEEQ_BLOCK), 0, (hipStream_t)stream, n,
-                       src, dst);
+    hipLaunchKernelGGL(fiveeq::stream_copy_kernel, dim3((unsigned)(member_blocks(n) < 8192 ? member_blocks(n) : 8192)), dim3(FIVEEQ_BLOCK), 0,
+                       (hipStream_t)stream, n, src, dst);
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;
 }

@@ -24,16 +24,6 @@
 #ifndef FIVEEQ_MODEL_LDS
 #define FIVEEQ_MODEL_LDS 1        // 1: shared model constants staged in LDS; 0: kernarg -> SGPRs
 #endif
-// Members per lane in the per-step kernel.  Measured on MI355X (profiles/r01/ab_variants.txt):
-// 16 B/lane (fp64 x2) is within +-1 % of 8 B/lane at 1M and 8M members, and fp32 x4 is 19 % SLOWER
-// at 1M (182 VGPRs -> 2 waves/SIMD).  The path is bound by HBM/Infinity-Cache throughput, not by
-// access width, so the default stays one member per lane; the wide path is kept selectable.
-#ifndef FIVEEQ_MPL_F64
-#define FIVEEQ_MPL_F64 1
-#endif
-#ifndef FIVEEQ_MPL_F32
-#define FIVEEQ_MPL_F32 1
-#endif
 #ifndef FIVEEQ_FUSED_CHUNK
 #define FIVEEQ_FUSED_CHUNK 125    // drive-table steps staged into LDS per refill (fused kernel)
 #endif
@@ -258,39 +248,49 @@ __device__ __forceinline__ void store_stream(T* p, T v) {
 }
 
 // ---------------------------------------------------------------------------------
+// Per-wave summary statistics of T for one step: (sum, sum of squares, min, max) over the wave's
+// active members, in fp64, written to stats[(t * n_waves + wave) * 4 .. +3].  The 64 lanes fold
+// into a wave-private LDS slot with native LDS fp64 atomics (ds_add_f64 / ds_min_f64 /
+// ds_max_f64): they issue on the LDS pipe, beside the VALU stream, and a wave's LDS operations
+// complete in program order, so no barrier is needed.  One 32-byte record per wave and step
+// (0.5 B per member-step) replaces the T trajectory when only moments are wanted.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void wave_stats(double* slot, const bool active, const T Tn, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 4) slot[lane] = lane == 2 ? __builtin_inf() : (lane == 3 ? -__builtin_inf() : 0.0);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (active) {
+        const double v = (double)Tn;
+        atomicAdd(&slot[0], v);
+        atomicAdd(&slot[1], v * v);
+        atomicMin(&slot[2], v);
+        atomicMax(&slot[3], v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < 4) out[lane] = slot[lane];
+}
+
+// ---------------------------------------------------------------------------------
 // Kernel 1 — ONE TIMESTEP PER LAUNCH (the north-star form).
 // Per member-step HBM traffic (elements): read SP + 2 (state) + 3G + 2 (params),
 // write SP + 2 (state) + G + 1 (C, T rows)  ->  A = w (2 SP + 4 G + 7) bytes
 // (152 B CO2-only fp64, 248 B for pools 4+1+1 fp64).
-// The shared drive record of this step is staged through LDS once per workgroup.
-// Grid-stride over members; block b always touches the same members in every launch,
-// so whatever state survives in its XCD's L2 / the Infinity Cache is re-hit next step.
+// The step's drive record — emissions, cumulative emissions, F_ext and the OUTPUT ROW this step
+// is stored at (drive[t][7]; negative = not stored) — is staged through LDS once per workgroup,
+// next to the shared model.  One member per lane, workgroup b owns members [256 b, 256 b + 256)
+// in every launch, so whatever state survives in its XCD's L2 / the Infinity Cache is re-hit by
+// the same XCD next step (workgroups b and b + 8 share an XCD under round-robin dispatch).
 // ---------------------------------------------------------------------------------
-template <typename T, int MPL>
-struct VecOf { using type = T __attribute__((ext_vector_type(MPL))); };
-template <typename T>
-struct VecOf<T, 1> { using type = T; };
-template <typename T, int MPL>
-__device__ __forceinline__ T vec_get(const typename VecOf<T, MPL>::type& v, int j) {
-    if constexpr (MPL == 1) return v; else return v[j];
-}
-template <typename T, int MPL>
-__device__ __forceinline__ void vec_set(typename VecOf<T, MPL>::type& v, int j, T x) {
-    if constexpr (MPL == 1) v = x; else v[j] = x;
-}
-
-// MPL = members per lane: each lane owns MPL CONSECUTIVE members and moves every row with one
-// MPL-wide vector access (fp64 x2 = 16 B/lane = 1 KiB per wave-instruction, the widest form).
-// The host picks MPL > 1 only when ld and every row base are MPL-aligned; the n % MPL tail
-// members are stepped by the first lanes of workgroup 0 through the scalar path.
-template <typename T, int P0, int P1, int P2, int MPL>
+template <typename T, int P0, int P1, int P2>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
     const KModel<T> km, const T* __restrict__ drive, const int t, const int64_t n, const int64_t ld,
     const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
-    T* __restrict__ C_row /* [G][ld] of step t, or nullptr */, T* __restrict__ T_row /* [ld] or nullptr */) {
+    T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
+    const int n_rows, double* __restrict__ stats /* [n_steps][n_waves][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
-    using VT = typename VecOf<T, MPL>::type;
     __shared__ T drv[DRIVE_STRIDE];
+    __shared__ double wslot[FIVEEQ_BLOCK / 64][4];
 #if FIVEEQ_MODEL_LDS
     __shared__ KModel<T> km_s;
     stage_model(&km_s);
@@ -301,82 +301,46 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
     if (threadIdx.x < DRIVE_STRIDE) drv[threadIdx.x] = drive[(int64_t)t * DRIVE_STRIDE + threadIdx.x];
     __syncthreads();
 
-    const int64_t nv = n / MPL;                       // lanes' worth of full member groups
-    const int64_t stride = (int64_t)gridDim.x * FIVEEQ_BLOCK;
-    for (int64_t v = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x; v < nv; v += stride) {
-        const int64_t m = v * MPL;
-        VT rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tv;
+    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
+    const bool active = m < n;
+    T Tn = T(0);
+    if (active) {
+        T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G];
 #pragma unroll
-        for (int k = 0; k < L::SP; ++k) Rv[k] = *reinterpret_cast<const VT*>(&R[k * ld + m]);
+        for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + m];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) Sv[k] = *reinterpret_cast<const VT*>(&S[k * ld + m]);
+        for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + m];
 #pragma unroll
-        for (int k = 0; k < 3 * L::G; ++k) rr[k] = *reinterpret_cast<const VT*>(&r[k * ld + m]);
+        for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + m];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) qq[k] = *reinterpret_cast<const VT*>(&q[k * ld + m]);
+        for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + m];
+
+        member_step<T, L>(kmr, drv, rr, qq, Rv, Sv, Cv, Tn);
 
 #pragma unroll
-        for (int j = 0; j < MPL; ++j) {
-            T r1[3 * L::G], q1[2], R1[L::SP], S1[2], C1[L::G], T1;
+        for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
 #pragma unroll
-            for (int k = 0; k < L::SP; ++k) R1[k] = vec_get<T, MPL>(Rv[k], j);
+        for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+        const int64_t row = (int64_t)drv[7];
+        if (row >= 0 && row < n_rows) {
+            if (C_traj != nullptr) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) S1[k] = vec_get<T, MPL>(Sv[k], j);
-#pragma unroll
-            for (int k = 0; k < 3 * L::G; ++k) r1[k] = vec_get<T, MPL>(rr[k], j);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) q1[k] = vec_get<T, MPL>(qq[k], j);
-            member_step<T, L>(kmr, drv, r1, q1, R1, S1, C1, T1);
-#pragma unroll
-            for (int k = 0; k < L::SP; ++k) vec_set<T, MPL>(Rv[k], j, R1[k]);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) vec_set<T, MPL>(Sv[k], j, S1[k]);
-#pragma unroll
-            for (int g = 0; g < L::G; ++g) vec_set<T, MPL>(Cv[g], j, C1[g]);
-            vec_set<T, MPL>(Tv, j, T1);
-        }
-
-#pragma unroll
-        for (int k = 0; k < L::SP; ++k) *reinterpret_cast<VT*>(&R[k * ld + m]) = Rv[k];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) *reinterpret_cast<VT*>(&S[k * ld + m]) = Sv[k];
-        if (C_row != nullptr) {
-#pragma unroll
-            for (int g = 0; g < L::G; ++g) store_stream(reinterpret_cast<VT*>(&C_row[g * ld + m]), Cv[g]);
-        }
-        if (T_row != nullptr) store_stream(reinterpret_cast<VT*>(&T_row[m]), Tv);
-    }
-
-    if constexpr (MPL > 1) {                          // ragged tail: fewer than MPL members
-        const int64_t m = nv * MPL + threadIdx.x;
-        if (blockIdx.x == 0 && m < n) {
-            T r1[3 * L::G], q1[2], R1[L::SP], S1[2], C1[L::G], T1;
-#pragma unroll
-            for (int k = 0; k < L::SP; ++k) R1[k] = R[k * ld + m];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) S1[k] = S[k * ld + m];
-#pragma unroll
-            for (int k = 0; k < 3 * L::G; ++k) r1[k] = r[k * ld + m];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) q1[k] = q[k * ld + m];
-            member_step<T, L>(kmr, drv, r1, q1, R1, S1, C1, T1);
-#pragma unroll
-            for (int k = 0; k < L::SP; ++k) R[k * ld + m] = R1[k];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) S[k * ld + m] = S1[k];
-            if (C_row != nullptr) {
-#pragma unroll
-                for (int g = 0; g < L::G; ++g) store_stream(&C_row[g * ld + m], C1[g]);
+                for (int g = 0; g < L::G; ++g) store_stream(&C_traj[(row * L::G + g) * ld + m], Cv[g]);
             }
-            if (T_row != nullptr) store_stream(&T_row[m], T1);
+            if (T_traj != nullptr) store_stream(&T_traj[row * ld + m], Tn);
         }
+    }
+    if (stats != nullptr) {
+        const int64_t n_waves = (n + 63) >> 6;
+        const int64_t wave = (int64_t)blockIdx.x * (FIVEEQ_BLOCK / 64) + (threadIdx.x >> 6);
+        if (wave < n_waves) wave_stats(wslot[threadIdx.x >> 6], active, Tn, stats + ((int64_t)t * n_waves + wave) * 4);
     }
 }
 
 // ---------------------------------------------------------------------------------
 // Kernel 2 — TIME-FUSED: one launch advances [t_begin, t_end); a member's state and
 // parameters stay in registers for the whole span, the drive table is staged into LDS
-// FIVEEQ_FUSED_CHUNK steps at a time, and only the C/T trajectory rows go to HBM.
+// FIVEEQ_FUSED_CHUNK steps at a time, and only the C/T rows of stored steps go to HBM.
 // Per member-step traffic: w (G + 1) + w (2 SP + 3 G + 6) / n_steps.
 // Same member_step() as kernel 1: results are bit-identical.
 // ---------------------------------------------------------------------------------
@@ -385,9 +349,11 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const KModel<T> km, const T* __restrict__ drive, const int t_begin, const int t_end,
     const int64_t n, const int64_t ld,
     const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
-    T* __restrict__ C_traj /* [n_steps][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_steps][ld] or nullptr */) {
+    T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
+    const int n_rows, double* __restrict__ stats /* [n_steps][n_waves][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
+    __shared__ double wslot[FIVEEQ_BLOCK / 64][4];
 #if FIVEEQ_MODEL_LDS
     __shared__ KModel<T> km_s;
     stage_model(&km_s);
@@ -399,6 +365,9 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
     const bool active = m < n;
     const int64_t mm = active ? m : 0;    // idle tail lanes shadow member 0 and store nothing
+    const int64_t n_waves = (n + 63) >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * (FIVEEQ_BLOCK / 64) + (threadIdx.x >> 6);
+    const bool wave_live = stats != nullptr && wave < n_waves;
 
     T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
 #pragma unroll
@@ -417,15 +386,18 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
             drv[i] = drive[(int64_t)tc * DRIVE_STRIDE + i];
         __syncthreads();
         for (int k = 0; k < nt; ++k) {
-            member_step<T, L>(kmr, &drv[k * DRIVE_STRIDE], rr, qq, Rv, Sv, Cv, Tn);
-            if (active) {
-                const int64_t t = tc + k;
+            const T* d = &drv[k * DRIVE_STRIDE];
+            member_step<T, L>(kmr, d, rr, qq, Rv, Sv, Cv, Tn);
+            const int64_t row = (int64_t)d[7];
+            if (active && row >= 0 && row < n_rows) {
                 if (C_traj != nullptr) {
 #pragma unroll
-                    for (int g = 0; g < L::G; ++g) store_stream(&C_traj[(t * L::G + g) * ld + m], Cv[g]);
+                    for (int g = 0; g < L::G; ++g) store_stream(&C_traj[(row * L::G + g) * ld + m], Cv[g]);
                 }
-                if (T_traj != nullptr) store_stream(&T_traj[t * ld + m], Tn);
+                if (T_traj != nullptr) store_stream(&T_traj[row * ld + m], Tn);
             }
+            if (wave_live)
+                wave_stats(wslot[threadIdx.x >> 6], active, Tn, stats + ((int64_t)(tc + k) * n_waves + wave) * 4);
         }
     }
     if (active) {

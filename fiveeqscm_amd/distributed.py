@@ -67,6 +67,29 @@ def percentiles_sorted(xs, percentiles):
     return torch.stack(cols, dim=1)
 
 
+def moments_from_sums(sums):
+    """sums [n, 5] = (count, sum, sum of squares, min, max) -> dict of [n] tensors."""
+    cnt, s1, s2 = sums[:, 0], sums[:, 1], sums[:, 2]
+    mean = s1 / cnt
+    return {"count": cnt, "mean": mean, "var": (s2 / cnt - mean * mean).clamp_min(0.0), "min": sums[:, 3],
+            "max": sums[:, 4]}
+
+
+def reduce_stats(sums, group=None):
+    """All-reduce the per-shard (count, sum, sum^2, min, max) records of every step over the ranks
+    (three tiny collectives: SUM on the first three columns, MIN, MAX) and return the ensemble
+    moments on every rank.  This is all a run without stored trajectories has to exchange."""
+    dist, _, world = _dist(group)
+    sums = sums.clone()
+    if world > 1:
+        add, mn, mx = sums[:, :3].contiguous(), sums[:, 3].contiguous(), sums[:, 4].contiguous()
+        dist.all_reduce(add, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        sums = torch.cat([add, mn[:, None], mx[:, None]], dim=1)
+    return moments_from_sums(sums)
+
+
 def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None):
     """rows [K, n_local]: this rank's members at K output times.  Collective over `group`.
     Returns on every rank a dict with the merged moments (mean, var, min, max, count; [K] each, fp64);

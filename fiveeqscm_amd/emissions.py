@@ -37,9 +37,11 @@ def emissions_sha256(E):
     return hashlib.sha256(np.ascontiguousarray(E, dtype=np.float64).tobytes()).hexdigest()
 
 
-def make_drive(emissions, F_ext=None, dt=1.0):
+def make_drive(emissions, F_ext=None, dt=1.0, output_steps=None):
     """emissions [n_steps, G] (or [n_steps]) -> drive [n_steps, 8] fp64 (include/fiveeq.h):
-    cols 0..2 E_g, cols 3..5 cumulative emissions BEFORE the step, col 6 F_ext, col 7 pad."""
+    cols 0..2 E_g, cols 3..5 cumulative emissions BEFORE the step, col 6 F_ext, col 7 the output
+    row the step's C/T are stored at (-1: not stored).  output_steps=None stores every step at
+    row t; otherwise the listed steps are stored at rows 0, 1, ... in increasing step order."""
     E = np.asarray(emissions, dtype=np.float64)
     if E.ndim == 1:
         E = E[:, None]
@@ -56,4 +58,12 @@ def make_drive(emissions, F_ext=None, dt=1.0):
         if F_ext.shape[0] != n_steps:
             raise ValueError(f"F_ext has {F_ext.shape[0]} steps, emissions {n_steps}")
         drive[:, 6] = F_ext
+    if output_steps is None:
+        drive[:, 7] = np.arange(n_steps)
+    else:
+        steps = np.unique(np.asarray(output_steps, dtype=np.int64).reshape(-1))
+        if steps.size and (steps[0] < 0 or steps[-1] >= n_steps):
+            raise ValueError(f"output_steps outside [0, {n_steps})")
+        drive[:, 7] = -1.0
+        drive[steps, 7] = np.arange(steps.size)
     return drive

@@ -6,9 +6,10 @@ Data layout in HBM (struct-of-arrays over members; N = members of this shard):
     q      [2,  N]   thermal-box coefficients
     R      [SP, N]   pool contents, gas-major (SP = sum of active pools)
     S      [2,  N]   thermal-box temperatures
-    drive  [n_steps, 8]   shared: E_g, cumulative E_g before the step, F_ext
-    C      [n_steps, G, N]   concentration trajectory   (optional)
-    T      [n_steps, N]      temperature trajectory     (optional)
+    drive  [n_steps, 8]   shared: E_g, cumulative E_g before the step, F_ext, output row
+    C      [n_rows, G, N]    concentrations of the stored steps (all steps, a selection, or none)
+    T      [n_rows, N]       temperature of the stored steps
+    T_stats[n_steps, W, 4]   optional per-wave (sum, sum^2, min, max) of T, W = ceil(N/64), fp64
 
 There is no CPU path: constructing an engine without a GPU, or without the built
 HIP library, raises.  (The reference's own function, `calculate_hfc_conc`, is a
@@ -43,7 +44,11 @@ class EnsembleEngine:
     """Advance N ensemble members of the five-equation model on one MI355X."""
 
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
-                 device=None, store_trajectory=True, R0=None, S0=None, lib_path=None):
+                 device=None, store_trajectory=True, output_steps=None, collect_stats=False,
+                 R0=None, S0=None, lib_path=None):
+        """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
+        stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
+        collect_stats: also accumulate per-step ensemble moments of T on the device (`stats()`)."""
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.lib = _capi.load(lib_path)    # raises if the HIP library is not built
@@ -67,7 +72,11 @@ class EnsembleEngine:
         if not self.lib.fiveeq_layout_supported(G, n_pools):
             raise _capi.FiveEqError(_capi.E_UNSUPPORTED, f"pool layout {self.pools} has no compiled kernel")
 
-        drive = make_drive(emissions, F_ext, dt)
+        if not store_trajectory:
+            output_steps = []
+        drive = make_drive(emissions, F_ext, dt, output_steps)
+        self.out_steps = np.nonzero(drive[:, 7] >= 0)[0]          # step index of each stored row
+        self.n_rows = int(self.out_steps.size)
         if drive[:, G:3].any():
             raise ValueError("emissions carry more gases than the parameter set")
         self.n_steps = int(drive.shape[0])
@@ -81,8 +90,11 @@ class EnsembleEngine:
             self.q = torch.from_numpy(np.ascontiguousarray(_rows(params["q"], 2, N, "q"))).to(dev, dt_).contiguous()
             self.R = torch.zeros((SP, N), dtype=dt_, device=dev)
             self.S = torch.zeros((2, N), dtype=dt_, device=dev)
-            self.C = torch.empty((self.n_steps, G, N), dtype=dt_, device=dev) if store_trajectory else None
-            self.T = torch.empty((self.n_steps, N), dtype=dt_, device=dev) if store_trajectory else None
+            self.C = torch.empty((self.n_rows, G, N), dtype=dt_, device=dev) if self.n_rows else None
+            self.T = torch.empty((self.n_rows, N), dtype=dt_, device=dev) if self.n_rows else None
+            self.n_waves = int(self.lib.fiveeq_stats_waves(N))
+            self.T_stats = (torch.zeros((self.n_steps, self.n_waves, 4), dtype=torch.float64, device=dev)
+                            if collect_stats else None)
         self._R0 = None if R0 is None else np.asarray(R0, dtype=np.float64).reshape(SP, N)
         self._S0 = None if S0 is None else np.asarray(S0, dtype=np.float64).reshape(2, N)
         self.reset_state()
@@ -112,7 +124,7 @@ class EnsembleEngine:
         N = self.n_members
         return (ctypes.byref(self.model), N, N, self._ptr(self.drive), self.n_steps, int(t_begin), int(t_end),
                 self._ptr(self.r), self._ptr(self.q), self._ptr(self.R), self._ptr(self.S),
-                self._ptr(self.C), self._ptr(self.T))
+                self._ptr(self.C), self._ptr(self.T), self.n_rows, self._ptr(self.T_stats))
 
     def step(self, t, stream=None):
         """One timestep = one kernel launch (asynchronous)."""
@@ -121,7 +133,8 @@ class EnsembleEngine:
         with torch.cuda.device(self.device):
             rc = fn(ctypes.byref(self.model), N, N, self._ptr(self.drive), self.n_steps, int(t),
                     self._ptr(self.r), self._ptr(self.q), self._ptr(self.R), self._ptr(self.S),
-                    self._ptr(self.C), self._ptr(self.T), self._stream(stream))
+                    self._ptr(self.C), self._ptr(self.T), self.n_rows, self._ptr(self.T_stats),
+                    self._stream(stream))
         _capi.check(self.lib, rc)
 
     def run(self, t_begin=0, t_end=None, mode="per_step", stream=None):
@@ -167,6 +180,24 @@ class EnsembleEngine:
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
+    # -- on-device summary statistics -----------------------------------------------------
+    def stats_sums(self, t_begin=0, t_end=None):
+        """[n, 5] fp64 per step: (count, sum T, sum T^2, min T, max T) over this shard's members,
+        folded over the per-wave records the kernels wrote.  Additive across shards
+        (fiveeqscm_amd.distributed.reduce_stats)."""
+        if self.T_stats is None:
+            raise RuntimeError("engine was built with collect_stats=False")
+        t_end = self.n_steps if t_end is None else int(t_end)
+        s = self.T_stats[t_begin:t_end]
+        cnt = torch.full((s.shape[0],), float(self.n_members), dtype=torch.float64, device=s.device)
+        return torch.stack([cnt, s[:, :, 0].sum(1), s[:, :, 1].sum(1), s[:, :, 2].min(1).values,
+                            s[:, :, 3].max(1).values], dim=1)
+
+    def stats(self, t_begin=0, t_end=None):
+        """dict of per-step ensemble moments of T over this shard: mean, var (population), min, max."""
+        from .distributed import moments_from_sums
+        return moments_from_sums(self.stats_sums(t_begin, t_end))
+
     # -- accounting ----------------------------------------------------------------------
     def bytes_per_member_step(self, mode="per_step"):
         """ALGORITHMIC HBM bytes per member-timestep:
@@ -174,20 +205,23 @@ class EnsembleEngine:
         fused:    w (G + 1) + w (2 SP + 3 G + 6) / n_steps."""
         w = 8 if self.dtype == torch.float64 else 4
         G, SP = self.n_gas, self.sum_pools
-        out = (G + 1) if self.C is not None else 0
+        out = (G + 1) * self.n_rows / self.n_steps            # stored rows only
+        extra = (32.0 / 64.0) if self.T_stats is not None else 0.0   # one 32-B stats record per wave
         if mode == "fused":
-            return w * (out + (2 * SP + 3 * G + 6) / self.n_steps)
-        return w * (2 * SP + 3 * G + 6 + out)
+            return w * (out + (2 * SP + 3 * G + 6) / self.n_steps) + extra
+        return w * (2 * SP + 3 * G + 6 + out) + extra
 
 
 def run_ensemble(emissions, params, n_members, *, F_ext=None, dt=1.0, dtype=torch.float64, device=None,
-                 mode="per_step", R0=None, S0=None):
-    """Whole-series convenience wrapper: returns dict(C [n_steps,G,N], T [n_steps,N], R, S) of
-    device tensors after a synchronise."""
+                 mode="per_step", output_steps=None, collect_stats=False, R0=None, S0=None):
+    """Whole-series convenience wrapper: returns dict(C [n_rows,G,N], T [n_rows,N], R, S, out_steps
+    [, T_stats]) of device tensors after a synchronise."""
     eng = EnsembleEngine(params, n_members, emissions, F_ext=F_ext, dt=dt, dtype=dtype, device=device,
-                         R0=R0, S0=S0)
+                         output_steps=output_steps, collect_stats=collect_stats, R0=R0, S0=S0)
     eng.run(mode=mode)
     torch.cuda.synchronize(eng.device)
-    out = {"C": eng.C, "T": eng.T, "R": eng.R, "S": eng.S}
+    out = {"C": eng.C, "T": eng.T, "R": eng.R, "S": eng.S, "out_steps": eng.out_steps}
+    if collect_stats:
+        out["T_stats"] = eng.stats()
     eng.close()
     return out

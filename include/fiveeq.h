@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   1
+#define FIVEEQ_ABI_VERSION   2
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
@@ -85,15 +85,23 @@ typedef struct fiveeq_model {
 } fiveeq_model;
 
 /* Array shapes used below (G = n_gas, SP = sum of n_pools over gases):
- *   drive  dev [n_steps][8]   shared by all members, per step:
- *                             [0..2] E_g (emission rate), [3..5] cumulative
- *                             emissions BEFORE the step, [6] F_ext, [7] pad
- *   r      dev [3*G][ld]      rows g*3+0/1/2 = r0, rC, rT of gas g (per member)
- *   q      dev [2][ld]        thermal-box coefficients (per member)
- *   R      dev [SP][ld]       pool contents, gas-major, in/out
- *   S      dev [2][ld]        thermal-box temperatures, in/out
- *   C_traj dev [n_steps][G][ld]  concentrations per step (may be NULL: not stored)
- *   T_traj dev [n_steps][ld]     temperature per step    (may be NULL: not stored)
+ *   drive   dev [n_steps][8]   shared by all members, per step:
+ *                              [0..2] E_g (emission rate), [3..5] cumulative emissions BEFORE
+ *                              the step, [6] F_ext, [7] OUTPUT ROW of this step: the step's C and
+ *                              T are stored at row k = (int)drive[t][7] of C_traj / T_traj if
+ *                              0 <= k < n_rows, and not stored otherwise (store every step:
+ *                              drive[t][7] = t, n_rows = n_steps)
+ *   r       dev [3*G][ld]      rows g*3+0/1/2 = r0, rC, rT of gas g (per member)
+ *   q       dev [2][ld]        thermal-box coefficients (per member)
+ *   R       dev [SP][ld]       pool contents, gas-major, in/out
+ *   S       dev [2][ld]        thermal-box temperatures, in/out
+ *   C_traj  dev [n_rows][G][ld]  concentrations of the stored steps (may be NULL)
+ *   T_traj  dev [n_rows][ld]     temperature of the stored steps    (may be NULL)
+ *   T_stats dev [n_steps][W][4]  fp64 (also for the f32 entry points), W = fiveeq_stats_waves(n_members):
+ *                              per step and per wave of 64 members (sum T, sum T^2, min T, max T);
+ *                              summing over W gives the ensemble moments of every step without a
+ *                              stored trajectory (may be NULL).  Every step in the range writes all
+ *                              W records of its row.
  */
 
 /* new — library identification */
@@ -103,30 +111,32 @@ const char *fiveeq_last_error(void);
 int64_t     fiveeq_sizeof_model(void);
 /* new — 1 if (n_gas, n_pools[]) has a compiled kernel, else 0 */
 int         fiveeq_layout_supported(int32_t n_gas, const int32_t *n_pools);
+/* new — W of T_stats: ceil(n_members / 64) */
+int64_t     fiveeq_stats_waves(int64_t n_members);
 
 /* ONE TIMESTEP, ONE LAUNCH: the north-star hot path.  Stands where the
  * reference intended step_conc + alpha_val + step_forc + step_temp
  * (.coveragerc:12-14,17 — names only; no reference code exists).
- * Reads state/params from HBM, writes state back, writes C_traj[t], T_traj[t]. */
+ * Reads state/params from HBM, writes state back, writes the step's C, T rows and stats. */
 int fiveeq_step_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
                     const double *drive, int32_t n_steps, int32_t t,
                     const double *r, const double *q, double *R, double *S,
-                    double *C_traj, double *T_traj, void *stream);
+                    double *C_traj, double *T_traj, int32_t n_rows, double *T_stats, void *stream);
 int fiveeq_step_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
                     const float *drive, int32_t n_steps, int32_t t,
                     const float *r, const float *q, float *R, float *S,
-                    float *C_traj, float *T_traj, void *stream);
+                    float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, void *stream);
 
 /* Steps t_begin <= t < t_end as (t_end - t_begin) launches of the kernel above,
  * enqueued back-to-back on `stream` from C (no Python per step). */
 int fiveeq_run_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
                    const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
                    const double *r, const double *q, double *R, double *S,
-                   double *C_traj, double *T_traj, void *stream);
+                   double *C_traj, double *T_traj, int32_t n_rows, double *T_stats, void *stream);
 int fiveeq_run_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
                    const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
                    const float *r, const float *q, float *R, float *S,
-                   float *C_traj, float *T_traj, void *stream);
+                   float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, void *stream);
 
 /* The same launch sequence captured once into a hipGraph ("plan") and replayed:
  * removes per-launch host cost for small ensembles.  The plan bakes in the
@@ -134,25 +144,25 @@ int fiveeq_run_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
 int fiveeq_plan_create_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
                            const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
                            const double *r, const double *q, double *R, double *S,
-                           double *C_traj, double *T_traj, void **plan_out);
+                           double *C_traj, double *T_traj, int32_t n_rows, double *T_stats, void **plan_out);
 int fiveeq_plan_create_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
                            const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
                            const float *r, const float *q, float *R, float *S,
-                           float *C_traj, float *T_traj, void **plan_out);
+                           float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, void **plan_out);
 int fiveeq_plan_launch(void *plan, void *stream);
 int fiveeq_plan_destroy(void *plan);
 
 /* TIME-FUSED variant: one launch advances t_begin..t_end with
- * the member's state held in registers; only C_traj/T_traj rows are written per
+ * the member's state held in registers; only the stored C/T rows and the stats are written per
  * step.  Same arithmetic, bit-identical results to the per-step path. */
 int fiveeq_run_fused_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
                          const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
                          const double *r, const double *q, double *R, double *S,
-                         double *C_traj, double *T_traj, void *stream);
+                         double *C_traj, double *T_traj, int32_t n_rows, double *T_stats, void *stream);
 int fiveeq_run_fused_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
                          const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
                          const float *r, const float *q, float *R, float *S,
-                         float *C_traj, float *T_traj, void *stream);
+                         float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, void *stream);
 
 /* Ensemble form of the reference's one function,
  *   calculate_hfc_conc(emissions, time, lifetime) = emissions[0]*exp(-time)

@@ -27,6 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_capi.SIGNATURES) == names, "ctypes binding and header disagree"
     assert lib.fiveeq_abi_version() == _capi.ABI_VERSION
     assert lib.fiveeq_sizeof_model() == ctypes.sizeof(_capi.Model) == 448
+    assert [lib.fiveeq_stats_waves(n) for n in (0, 1, 64, 65, 1_000_000)] == [0, 1, 1, 2, 15625]
 
 
 def test_missing_library_fails_loudly(tmp_path):
@@ -45,7 +46,7 @@ def test_layout_supported():
 
 def _call_step(lib, model, n=8, ld=8, n_steps=4, t=0, ptr=0x1000):
     p = ctypes.c_void_p(ptr)
-    return lib.fiveeq_step_f64(ctypes.byref(model), n, ld, p, n_steps, t, p, p, p, p, None, None, None)
+    return lib.fiveeq_step_f64(ctypes.byref(model), n, ld, p, n_steps, t, p, p, p, p, None, None, 0, None, None)
 
 
 def test_validation_rejects_bad_arguments_before_any_launch():
@@ -88,7 +89,8 @@ def test_validation_rejects_bad_arguments_before_any_launch():
     ]
     for edit, want in bad_models:
         assert _call_step(lib, broken(edit)) == want
-    assert lib.fiveeq_step_f64(None, 8, 8, None, 4, 0, None, None, None, None, None, None, None) == _capi.E_INVALID
+    assert lib.fiveeq_step_f64(None, 8, 8, None, 4, 0, None, None, None, None, None, None, 0, None, None) \
+        == _capi.E_INVALID
     with pytest.raises(_capi.FiveEqError) as ei:
         _capi.check(lib, _call_step(lib, good, n=0))
     assert ei.value.code == _capi.E_INVALID
@@ -98,13 +100,14 @@ def test_run_and_plan_validation():
     lib = _capi.load()
     m = prm.make_model(prm.default_params("multigas"))
     p = ctypes.c_void_p(0x1000)
-    args = lambda tb, te: (ctypes.byref(m), 8, 8, p, 10, tb, te, p, p, p, p, None, None)  # noqa: E731
+    args = lambda tb, te, rows=0: (ctypes.byref(m), 8, 8, p, 10, tb, te, p, p, p, p, None, None, rows, None)  # noqa: E731
     assert lib.fiveeq_run_f64(*args(3, 2), None) == _capi.E_INVALID
     assert lib.fiveeq_run_f32(*args(0, 11), None) == _capi.E_INVALID
     assert lib.fiveeq_run_fused_f64(*args(-1, 2), None) == _capi.E_INVALID
     assert lib.fiveeq_run_f64(*args(5, 5), None) == _capi.OK            # empty range: nothing launched
     assert lib.fiveeq_run_fused_f32(*args(5, 5), None) == _capi.OK
     assert lib.fiveeq_plan_create_f64(*args(0, 11), None) == _capi.E_INVALID
+    assert lib.fiveeq_run_f64(*args(0, 5, -1), None) == _capi.E_INVALID        # n_rows < 0
     assert lib.fiveeq_plan_launch(None, None) == _capi.E_INVALID
     assert lib.fiveeq_plan_destroy(None) == _capi.E_INVALID
     assert lib.fiveeq_hfc_conc_f64(0, 0, 1, p, p, p, None) == _capi.E_INVALID
@@ -120,6 +123,18 @@ def test_engine_refuses_to_run_without_a_gpu():
     from fiveeqscm_amd.emissions import rcp_like_emissions
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         EnsembleEngine(prm.default_params("co2"), 16, rcp_like_emissions(10, 1))
+
+
+def test_drive_table_output_rows():
+    import numpy as np
+    from fiveeqscm_amd.emissions import make_drive
+    E = np.ones((6, 2))
+    assert make_drive(E)[:, 7].tolist() == [0, 1, 2, 3, 4, 5]
+    assert make_drive(E, output_steps=[4, 1, 4])[:, 7].tolist() == [-1, 0, -1, -1, 1, -1]
+    assert make_drive(E, output_steps=[])[:, 7].tolist() == [-1] * 6
+    with pytest.raises(ValueError):
+        make_drive(E, output_steps=[6])
+    assert make_drive(E, dt=0.5)[:, 3].tolist() == [0, 0.5, 1.0, 1.5, 2.0, 2.5]
 
 
 def test_make_model_packs_the_parameter_dict():

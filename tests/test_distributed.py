@@ -8,8 +8,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from fiveeqscm_amd.distributed import (gather_summary, local_moments, merge_moments, percentiles_sorted,
-                                       shard_bounds)
+from fiveeqscm_amd.distributed import (gather_summary, local_moments, merge_moments, moments_from_sums,
+                                       percentiles_sorted, reduce_stats, shard_bounds)
 
 
 def test_shard_bounds_cover_and_balance():
@@ -41,6 +41,14 @@ def test_percentiles_match_numpy():
     np.testing.assert_allclose(got, np.percentile(x, (0, 5, 50, 95, 100, 33.3), axis=1).T, rtol=1e-13)
 
 
+def test_moments_from_sums_single_process():
+    x = torch.tensor([[1.0, 2.0, 3.0, 6.0]], dtype=torch.float64)
+    sums = torch.tensor([[4.0, 12.0, 50.0, 1.0, 6.0]], dtype=torch.float64)
+    m = reduce_stats(sums)            # no process group: local only
+    assert m["mean"].item() == 3.0 and abs(m["var"].item() - x.var(unbiased=False).item()) < 1e-15
+    assert moments_from_sums(sums)["max"].item() == 6.0
+
+
 def test_single_process_summary_needs_no_process_group():
     x = torch.arange(12, dtype=torch.float64).reshape(2, 6)
     s = gather_summary(x, percentiles=(50.0,))
@@ -56,6 +64,14 @@ def _worker(rank, world, port, n_total, q):
         full = rng.normal(1.5, 0.7, size=(3, n_total))            # every rank can rebuild the global T rows
         lo, hi = shard_bounds(n_total, rank, world)
         s = gather_summary(torch.from_numpy(full[:, lo:hi].copy()), percentiles=(5.0, 50.0, 95.0))
+        x = torch.from_numpy(full[:, lo:hi].copy())
+        sums = torch.stack([torch.full((3,), float(hi - lo), dtype=torch.float64), x.sum(1), (x * x).sum(1),
+                            x.min(1).values, x.max(1).values], dim=1)
+        m = reduce_stats(sums)                                     # every rank gets the ensemble moments
+        stats_ok = (np.allclose(m["mean"].numpy(), full.mean(1), rtol=1e-13)
+                    and np.allclose(m["var"].numpy(), full.var(1), rtol=1e-10)
+                    and np.array_equal(m["min"].numpy(), full.min(1)) and np.array_equal(m["max"].numpy(), full.max(1))
+                    and m["count"].tolist() == [float(n_total)] * 3)
         if rank == 0:
             want = np.percentile(full, (5.0, 50.0, 95.0), axis=1).T
             ok = (np.allclose(s["percentiles"].numpy(), want, rtol=1e-13)
@@ -63,9 +79,9 @@ def _worker(rank, world, port, n_total, q):
                   and np.allclose(s["var"].numpy(), full.var(1), rtol=1e-12)
                   and s["count"].tolist() == [float(n_total)] * 3
                   and np.array_equal(s["min"].numpy(), full.min(1)) and np.array_equal(s["max"].numpy(), full.max(1)))
-            q.put(bool(ok))
+            q.put(bool(ok and stats_ok))
         else:
-            q.put(s["percentiles"] is None and abs(float(s["mean"][0]) - full[0].mean()) < 1e-12)
+            q.put(bool(stats_ok and s["percentiles"] is None and abs(float(s["mean"][0]) - full[0].mean()) < 1e-12))
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -243,6 +243,72 @@ def test_no_trajectory_mode_and_negative_concentration_guard(gpu):
     assert torch.equal(a.R, b.R) and torch.equal(a.S, b.S) and torch.equal(a.R, c.R) and torch.equal(a.S, c.S)
 
 
+def test_selected_output_steps(gpu):
+    """Only the listed steps are stored (rows in step order); everything else is bit-identical."""
+    N, n_steps = 700, 120
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    full = _engine(p, N, E)
+    full.run()
+    sel = [119, 3, 40, 41]
+    for mode in ("per_step", "fused", "graph"):
+        eng = _engine(p, N, E, output_steps=sel)
+        eng.run(mode=mode)
+        torch.cuda.synchronize()
+        assert eng.out_steps.tolist() == [3, 40, 41, 119] and eng.C.shape == (4, 3, N) and eng.T.shape == (4, N)
+        assert torch.equal(eng.C, full.C[[3, 40, 41, 119]]) and torch.equal(eng.T, full.T[[3, 40, 41, 119]])
+        assert torch.equal(eng.R, full.R) and torch.equal(eng.S, full.S)
+        eng.close()
+    # a drive table that names a row beyond n_rows must not write: run with n_rows = 2 through the C ABI
+    from fiveeqscm_amd import _capi
+    eng = _engine(p, N, E, output_steps=sel)
+    guard = torch.full_like(eng.T, -5.0)
+    eng.T = guard
+    eng.n_rows = 2
+    eng.run()
+    torch.cuda.synchronize()
+    assert torch.equal(guard[:2], full.T[[3, 40]]) and torch.all(guard[2:] == -5.0)
+    assert _capi.load() is eng.lib
+
+
+@pytest.mark.parametrize("mode", ["per_step", "fused", "graph"])
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 1000, 4096 + 37])
+def test_on_device_stats_match_trajectory(gpu, mode, N):
+    """Per-wave (sum, sum^2, min, max) records folded on the host == moments of the stored T rows
+    == moments of the oracle's T, for ragged wave/workgroup tails too."""
+    n_steps = 90
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    eng = _engine(p, N, E, collect_stats=True)
+    eng.run(mode=mode)
+    torch.cuda.synchronize()
+    st = eng.stats()
+    T = eng.T.cpu().numpy()
+    assert st["count"].tolist() == [float(N)] * n_steps
+    np.testing.assert_allclose(st["mean"].cpu().numpy(), T.mean(1), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(st["var"].cpu().numpy(), T.var(1), rtol=1e-8, atol=1e-16)
+    np.testing.assert_array_equal(st["min"].cpu().numpy(), T.min(1))
+    np.testing.assert_array_equal(st["max"].cpu().numpy(), T.max(1))
+    want = npo.run(E, p, N)["T"]
+    np.testing.assert_allclose(st["mean"].cpu().numpy(), want.mean(1), rtol=1e-10, atol=1e-13)
+    # stats without any stored trajectory: same records
+    eng2 = _engine(p, N, E, collect_stats=True, store_trajectory=False)
+    eng2.run(mode=mode)
+    torch.cuda.synchronize()
+    assert torch.equal(eng2.T_stats, eng.T_stats)
+
+
+def test_stats_fp32_accumulate_in_fp64(gpu):
+    N, n_steps = 5000, 60
+    p = prm.sample_ensemble(prm.default_params("co2"), N)
+    E = emi.rcp_like_emissions(n_steps, 1)
+    eng = _engine(p, N, E, dtype=torch.float32, collect_stats=True)
+    eng.run()
+    torch.cuda.synchronize()
+    T = eng.T.double().cpu().numpy()
+    np.testing.assert_allclose(eng.stats()["mean"].cpu().numpy(), T.mean(1), rtol=1e-13, atol=1e-15)
+
+
 def test_fp32_kernel_tracks_fp64_oracle(gpu):
     """BASELINE configs[4] runs fp32: stay within 2e-4 relative of the fp64 oracle over 750 steps
     (increment-form updates keep the tau = 1e6 yr pool alive in fp32)."""
@@ -299,7 +365,7 @@ def test_leading_dimension_subrange(gpu):
     R[:, lo:lo + N], S[:, lo:lo + N] = 0.0, 0.0
     off = lambda t: ctypes.c_void_p(t.data_ptr() + lo * 8)                              # noqa: E731
     rc = lib.fiveeq_run_f64(ctypes.byref(ref.model), N, ld, ctypes.c_void_p(ref.drive.data_ptr()), n_steps, 0,
-                            n_steps, off(r), off(q), off(R), off(S), off(C), off(T),
+                            n_steps, off(r), off(q), off(R), off(S), off(C), off(T), n_steps, None,
                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _capi.check(lib, rc)
     torch.cuda.synchronize()

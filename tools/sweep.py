@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--no-trajectory", action="store_true")
+    ap.add_argument("--stats", action="store_true", help="collect on-device T statistics")
     ap.add_argument("--scenario-steps", type=int, default=750, help="trajectory capacity (memory = steps*(G+1)*N*w)")
     a = ap.parse_args()
     G = 3 if a.kind == "multigas" else 1
@@ -45,7 +46,8 @@ def main():
         for dt in a.dtypes.split(","):
             dtype = torch.float64 if dt == "f64" else torch.float32
             engines = {lib: EnsembleEngine(p, N, E, dtype=dtype, device="cuda:0", lib_path=lib,
-                                           store_trajectory=not a.no_trajectory) for lib in libs}
+                                           store_trajectory=not a.no_trajectory, collect_stats=a.stats)
+                       for lib in libs}
             for mode in a.modes.split(","):
                 times = {lib: [] for lib in libs}
                 for rnd in range(a.rounds + 1):
