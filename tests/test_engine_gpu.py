@@ -99,6 +99,44 @@ def test_engine_bridge_to_reference_function(gpu, golden_hfc):
         np.testing.assert_allclose(got, ref[:, None] * (e0 / 10.0)[None, :], rtol=1e-13, atol=1e-15)
 
 
+def _one_pool(tau):
+    return {"a": [[1.0, 0, 0, 0]], "tau": [[tau, 1, 1, 1]], "r0": [tau * (-np.expm1(-100.0 / tau))], "rC": [0.0],
+            "rT": [0.0], "ra": [0.0], "PI_conc": [1.0], "emis2conc": [1.0], "f": [[0.0, 0.0, 0.0]], "iirf_max": 1e9,
+            "d": [239.0, 4.1], "q": [0.33, 0.41]}
+
+
+def test_constant_emissions_on_the_engine(gpu):
+    """The reference announces "test under constant emissions" (tests/unit/test_hfcs.py:15) but never
+    wrote it, and its function could not pass it (it only reads emissions[0]).  On the general engine:
+    one pool, alpha = 1, constant E  =>  R_k = E tau (1 - exp(-k/tau))."""
+    for tau in (1.0, 7.5, 52.0):
+        n, E = 80, 3.0
+        eng = _engine(_one_pool(tau), 70, np.full((n, 1), E))
+        eng.run()
+        torch.cuda.synchronize()
+        k = np.arange(1, n + 1)
+        want = E * tau * (1.0 - np.exp(-k / tau))
+        np.testing.assert_allclose(eng.C[:, 0, 5].cpu().numpy() - 1.0, want, rtol=1e-12)
+
+
+def test_pulse_not_in_year_zero_on_the_engine(gpu):
+    """The reference announces "test where pulse isn't in year zero" (tests/unit/test_hfcs.py:16).
+    A one-year emission of E in year k0 leaves E tau (1 - e^{-1/tau}) at the end of that year, which
+    then decays as exp(-(t - k0)/tau): the shape of calculate_hfc_conc shifted to the pulse year."""
+    from fiveeqscm_amd.concentrations import calculate_hfc_conc
+    tau, k0, n, E = 1.0, 7, 40, 10.0
+    em = np.zeros((n, 1))
+    em[k0, 0] = E
+    eng = _engine(_one_pool(tau), 3, em)
+    eng.run(mode="fused")
+    torch.cuda.synchronize()
+    got = eng.C[:, 0, 0].cpu().numpy() - 1.0
+    assert np.all(got[:k0] == 0.0)
+    landed = E * tau * (1.0 - np.exp(-1.0 / tau))
+    want = calculate_hfc_conc(np.array([landed]), np.arange(n - k0), lifetime=tau)       # the reference's shape
+    np.testing.assert_allclose(got[k0:], want, rtol=1e-12, atol=1e-16)
+
+
 # ---- five-equation parity at the BASELINE config shapes ------------------------------------------
 CASES = [
     pytest.param("co2", 1, 10_000, 750, id="config2-co2-10k"),          # BASELINE configs[1], full size

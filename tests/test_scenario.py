@@ -1,0 +1,50 @@
+"""Scenario I/O in the RCP emissions CSV layout."""
+import os
+
+import numpy as np
+import pytest
+
+from fiveeqscm_amd import emissions as emi
+from fiveeqscm_amd.scenario import read_emissions_csv, write_emissions_csv
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_read_rcp_layout_fixture():
+    years, E = read_emissions_csv(os.path.join(HERE, "golden", "rcp_layout_sample.csv"))
+    assert years.tolist() == [1765, 1766, 1767, 1768, 1769]
+    np.testing.assert_allclose(E[:, 0], [0.253, 0.264, 0.275, 0.286, 0.298])      # Fossil + Other
+    assert E[:, 1].tolist() == [10.5, 10.9, 11.3, 11.7, 12.1] and E[:, 2].tolist() == [0.61, 0.62, 0.63, 0.64, 0.65]
+    _, co2 = read_emissions_csv(os.path.join(HERE, "golden", "rcp_layout_sample.csv"), gases=("CO2",))
+    assert co2.shape == (5, 1)
+    with pytest.raises(ValueError, match="no column for HFC23"):
+        read_emissions_csv(os.path.join(HERE, "golden", "rcp_layout_sample.csv"), gases=("CO2", "HFC23"))
+
+
+def test_write_read_roundtrip_is_bit_exact(tmp_path):
+    E = emi.rcp_like_emissions(750, 3)
+    years = 1765 + np.arange(750)
+    path = tmp_path / "scen.csv"
+    write_emissions_csv(path, years, E)
+    y2, E2 = read_emissions_csv(path)
+    assert np.array_equal(y2, years) and E2.tobytes() == E.tobytes()
+    assert emi.emissions_sha256(E2) == emi.emissions_sha256(E)
+    np.testing.assert_array_equal(emi.make_drive(E2), emi.make_drive(E))
+
+
+def test_malformed_files(tmp_path):
+    p = tmp_path / "a.csv"
+    p.write_text("just text\nmore text\n")
+    with pytest.raises(ValueError, match="no column-name row"):
+        read_emissions_csv(p)
+    p.write_text("YEARS,FossilCO2,CH4,N2O\n")
+    with pytest.raises(ValueError, match="no numeric data"):
+        read_emissions_csv(p)
+    p.write_text("YEARS,FossilCO2,CH4,N2O\n2000,1,2,3\n2002,1,2,3\n2003,1,2,3\n")
+    with pytest.raises(ValueError, match="equal steps"):
+        read_emissions_csv(p)
+    p.write_text("YEARS,FossilCO2,CH4,N2O\n2000,1,,3\n2001,1,2,3\n")
+    with pytest.raises(ValueError, match="missing values"):
+        read_emissions_csv(p)
+    with pytest.raises(ValueError):
+        write_emissions_csv(p, [2000, 2001], np.zeros((3, 3)))
