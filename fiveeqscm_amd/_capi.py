@@ -80,6 +80,8 @@ SIGNATURES = {
     "fiveeq_run_fused_f32": (ctypes.c_int, _RUN_ARGS),
     "fiveeq_plan_create_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.POINTER(_p)]),
     "fiveeq_plan_create_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.POINTER(_p)]),
+    "fiveeq_run_inverse_f64": (ctypes.c_int, _RUN_ARGS[:11] + [_p] + _RUN_ARGS[11:]),
+    "fiveeq_run_inverse_f32": (ctypes.c_int, _RUN_ARGS[:11] + [_p] + _RUN_ARGS[11:]),
     "fiveeq_plan_launch": (ctypes.c_int, [_p, _p]),
     "fiveeq_plan_destroy": (ctypes.c_int, [_p]),
     "fiveeq_hfc_conc_f64": (ctypes.c_int, [_i64, _i64, _i32, _p, _p, _p, _p]),

@@ -122,6 +122,7 @@ KModel<T> make_kmodel(const fiveeq_model* m) {
     }
     for (int j = 0; j < 2; ++j) km.em1_d[j] = (T)std::expm1(-m->dt / m->d[j]);
     km.iirf_max = (T)m->iirf_max;
+    km.dt = (T)m->dt;
     return km;
 }
 
@@ -162,16 +163,17 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
     return FIVEEQ_OK;
 }
 
-template <typename T>
-int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, hipStream_t st) {
+template <typename T, bool INV>
+int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream_t st) {
     const int64_t blocks = member_blocks(a.n);
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_BLOCK);
     switch (a.code) {
-#define X(p0, p1, p2)                                                                               \
-    case (p0) * 100 + (p1) * 10 + (p2):                                                             \
-        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, t_begin, \
-                           t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);      \
+#define X(p0, p1, p2)                                                                                  \
+    case (p0) * 100 + (p1) * 10 + (p2):                                                                \
+        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV>), grid, block, 0, st, a.km, a.drive, t_begin, \
+                           t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj, a.T_traj, a.n_rows,   \
+                           a.stats);                                                                   \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X
@@ -220,7 +222,18 @@ int run_fused(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     RunArgs<T> a;
     if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
     if (t_begin == t_end) return FIVEEQ_OK;
-    return launch_fused(a, t_begin, t_end, (hipStream_t)stream);
+    return launch_fused<T, false>(a, t_begin, t_end, nullptr, (hipStream_t)stream);
+}
+
+template <typename T>
+int run_inverse(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
+                int32_t t_end, const T* r, const T* q, T* R, T* S, T* cumE, T* E_traj, T* T_traj, int n_rows,
+                double* stats, void* stream) {
+    RunArgs<T> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, E_traj, T_traj, n_rows, stats)) return rc;
+    if (!cumE) return fail(FIVEEQ_E_INVALID, "cumE is NULL");
+    if (t_begin == t_end) return FIVEEQ_OK;
+    return launch_fused<T, true>(a, t_begin, t_end, cumE, (hipStream_t)stream);
 }
 
 // ---- plans: the per-step launch sequence captured into a hipGraph --------------------------
@@ -339,6 +352,21 @@ int fiveeq_plan_create_f32(const fiveeq_model* model, int64_t n_members, int64_t
                            float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, void** plan_out) {
     return plan_create<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
                           plan_out);
+}
+
+int fiveeq_run_inverse_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
+                           int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q,
+                           double* R, double* S, double* cumE, double* E_traj, double* T_traj, int32_t n_rows,
+                           double* T_stats, void* stream) {
+    return run_inverse<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, cumE, E_traj, T_traj,
+                               n_rows, T_stats, stream);
+}
+int fiveeq_run_inverse_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
+                           int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
+                           float* S, float* cumE, float* E_traj, float* T_traj, int32_t n_rows, double* T_stats,
+                           void* stream) {
+    return run_inverse<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, cumE, E_traj, T_traj,
+                              n_rows, T_stats, stream);
 }
 
 int fiveeq_plan_launch(void* plan, void* stream) {

@@ -50,6 +50,7 @@ struct KModel {
     KGas<T> gas[MAX_GAS];
     T em1_d[2];                 // expm1(-dt/d_j), computed on the host in fp64
     T iirf_max;
+    T dt;
 };
 
 template <int P0, int P1, int P2>
@@ -168,10 +169,16 @@ __device__ __forceinline__ float fe_min(float a, float b) { return fminf(a, b); 
 //   rr  : per-member r0,rC,rT per gas ;  qq: per-member q_1,q_2
 //   R,S : in/out ;  C[g], Tnew: outputs
 // Every loop has compile-time bounds and is fully unrolled: arrays stay in VGPRs.
+//
+// INV = true is the concentration-driven (inverse) form: drv[g] holds the TARGET concentration
+// at the end of the step, the member's cumulative emissions cum[g] are per-member state, and
+// the emission rate that reaches the target is diagnosed from the same pool equations
+//     C* - C0 = sum_i R_i (1 + em1_i) - E alpha sum_i (a_i tau_i c) em1_i
+// and returned in out[g]; the pools are then advanced with that E.
 // ---------------------------------------------------------------------------------
-template <typename T, typename L, int g>
+template <typename T, typename L, int g, bool INV>
 __device__ __forceinline__ T gas_step(const KModel<T>& km, const T* __restrict__ drv, const T (&rr)[3 * L::G],
-                                      const T T_old, T (&R)[L::SP], T (&C)[L::G]) {
+                                      const T T_old, T (&R)[L::SP], T (&out)[L::G], T (&cum)[L::G]) {
 #if FIVEEQ_MODEL_LDS
     // compiler-only barrier: keeps this gas's LDS constant reads inside this gas's code instead of
     // all ~45 being hoisted to the kernel top (VGPR pressure) or out of the fused time loop
@@ -185,24 +192,40 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const T* __restrict__
 #pragma unroll
     for (int i = 1; i < P; ++i) sumR += R[o + i];
     const T G_a = sumR * kg.inv_c;
-    const T G_u = drv[3 + g] - G_a;
+    const T G_u = (INV ? cum[g] : drv[3 + g]) - G_a;
     T iirf = rr[3 * g] + rr[3 * g + 1] * G_u + rr[3 * g + 2] * T_old + kg.ra * G_a;
     iirf = fe_min(iirf, km.iirf_max);
     const T alpha = kg.g0 * fe_exp(iirf * kg.inv_g1);
     const T inv_alpha = fe_rcp(alpha);
-    const T Ea = drv[g] * alpha;
     // --- step_conc -----------------------------------------------------------------
+    T em1[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) em1[i] = fe_expm1_neg(kg.ndt_over_tau[i] * inv_alpha);
+    T E;
+    if constexpr (INV) {
+        T num = T(0), den = T(0);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            num += R[o + i] + R[o + i] * em1[i];
+            den += kg.atc[i] * em1[i];
+        }
+        E = (num - (drv[g] - kg.C0)) / (alpha * den);
+        cum[g] += E * km.dt;
+        out[g] = E;
+    } else {
+        E = drv[g];
+    }
+    const T Ea = E * alpha;
     T sumN = T(0);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const T em1 = fe_expm1_neg(kg.ndt_over_tau[i] * inv_alpha);
         const T Ri = R[o + i];
-        const T Rn = Ri + em1 * (Ri - kg.atc[i] * Ea);
+        const T Rn = Ri + em1[i] * (Ri - kg.atc[i] * Ea);
         R[o + i] = Rn;
         sumN += Rn;
     }
     const T Cg = kg.C0 + sumN;
-    C[g] = Cg;
+    if constexpr (!INV) out[g] = Cg;
     // --- step_forc (terms whose coefficient is zero are skipped: wave-uniform branch) ---
     const bool pos = Cg > T(0);
     T Fg = kg.f2 * (Cg - kg.C0);
@@ -211,19 +234,26 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const T* __restrict__
     return Fg;
 }
 
-template <typename T, typename L>
+template <typename T, typename L, bool INV = false>
 __device__ __forceinline__ void member_step(const KModel<T>& km, const T* __restrict__ drv,
                                             const T (&rr)[3 * L::G], const T (&qq)[2],
-                                            T (&R)[L::SP], T (&S)[2], T (&C)[L::G], T& Tnew) {
+                                            T (&R)[L::SP], T (&S)[2], T (&out)[L::G], T& Tnew, T (&cum)[L::G]) {
     const T T_old = S[0] + S[1];
     T F = drv[6];
-    F += gas_step<T, L, 0>(km, drv, rr, T_old, R, C);
-    if constexpr (L::G > 1) F += gas_step<T, L, 1>(km, drv, rr, T_old, R, C);
-    if constexpr (L::G > 2) F += gas_step<T, L, 2>(km, drv, rr, T_old, R, C);
+    F += gas_step<T, L, 0, INV>(km, drv, rr, T_old, R, out, cum);
+    if constexpr (L::G > 1) F += gas_step<T, L, 1, INV>(km, drv, rr, T_old, R, out, cum);
+    if constexpr (L::G > 2) F += gas_step<T, L, 2, INV>(km, drv, rr, T_old, R, out, cum);
     // --- step_temp -------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 2; ++j) S[j] = S[j] + km.em1_d[j] * (S[j] - qq[j] * F);
     Tnew = S[0] + S[1];
+}
+template <typename T, typename L>
+__device__ __forceinline__ void member_step(const KModel<T>& km, const T* __restrict__ drv,
+                                            const T (&rr)[3 * L::G], const T (&qq)[2],
+                                            T (&R)[L::SP], T (&S)[2], T (&C)[L::G], T& Tnew) {
+    T unused[L::G];
+    member_step<T, L, false>(km, drv, rr, qq, R, S, C, Tnew, unused);
 }
 
 // The shared model is the FIRST kernel argument (by value): its bytes sit at offset 0 of the
@@ -366,11 +396,15 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
 // Per member-step traffic: w (G + 1) + w (2 SP + 3 G + 6) / n_steps.
 // Same member_step() as kernel 1: results are bit-identical.
 // ---------------------------------------------------------------------------------
-template <typename T, int P0, int P1, int P2>
+//
+// INV = true: concentration-driven form.  drive[t][0..2] are target concentrations, cumE [G][ld] is
+// per-member cumulative-emission state (in/out), and C_traj receives the DIAGNOSED EMISSIONS.
+template <typename T, int P0, int P1, int P2, bool INV>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const KModel<T> km, const T* __restrict__ drive, const int t_begin, const int t_end,
     const int64_t n, const int64_t ld,
     const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
+    T* __restrict__ cumE /* [G][ld], INV only */,
     T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
     const int n_rows, double* __restrict__ stats /* [n_steps][n_waves][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
@@ -390,7 +424,11 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const int64_t wave = (int64_t)blockIdx.x * (FIVEEQ_BLOCK / 64) + (threadIdx.x >> 6);
     const bool wave_live = stats != nullptr && wave < n_waves;
 
-    T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
+    T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
+    if constexpr (INV) {
+#pragma unroll
+        for (int g = 0; g < L::G; ++g) cum[g] = cumE[g * ld + mm];
+    }
 #pragma unroll
     for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + mm];
 #pragma unroll
@@ -408,7 +446,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
         __syncthreads();
         for (int k = 0; k < nt; ++k) {
             const T* d = &drv[k * DRIVE_STRIDE];
-            member_step<T, L>(kmr, d, rr, qq, Rv, Sv, Cv, Tn);
+            member_step<T, L, INV>(kmr, d, rr, qq, Rv, Sv, Cv, Tn, cum);
             const int64_t row = (int64_t)d[7];
             if (active && row >= 0 && row < n_rows) {
                 if (C_traj != nullptr) {
@@ -426,6 +464,10 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
         for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
 #pragma unroll
         for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+        if constexpr (INV) {
+#pragma unroll
+            for (int g = 0; g < L::G; ++g) cumE[g * ld + m] = cum[g];
+        }
     }
 }
 

@@ -37,11 +37,13 @@ def emissions_sha256(E):
     return hashlib.sha256(np.ascontiguousarray(E, dtype=np.float64).tobytes()).hexdigest()
 
 
-def make_drive(emissions, F_ext=None, dt=1.0, output_steps=None):
+def make_drive(emissions, F_ext=None, dt=1.0, output_steps=None, concentration_driven=False):
     """emissions [n_steps, G] (or [n_steps]) -> drive [n_steps, 8] fp64 (include/fiveeq.h):
     cols 0..2 E_g, cols 3..5 cumulative emissions BEFORE the step, col 6 F_ext, col 7 the output
     row the step's C/T are stored at (-1: not stored).  output_steps=None stores every step at
-    row t; otherwise the listed steps are stored at rows 0, 1, ... in increasing step order."""
+    row t; otherwise the listed steps are stored at rows 0, 1, ... in increasing step order.
+    concentration_driven=True: `emissions` holds target concentrations (end of step) for the
+    inverse mode; cols 3..5 stay zero."""
     E = np.asarray(emissions, dtype=np.float64)
     if E.ndim == 1:
         E = E[:, None]
@@ -52,7 +54,8 @@ def make_drive(emissions, F_ext=None, dt=1.0, output_steps=None):
     n_steps, G = E.shape
     drive = np.zeros((n_steps, DRIVE_STRIDE), dtype=np.float64)
     drive[:, :G] = E
-    drive[1:, 3:3 + G] = np.cumsum(E * dt, axis=0)[:-1]
+    if not concentration_driven:          # inverse mode: cumulative emissions are per-member state
+        drive[1:, 3:3 + G] = np.cumsum(E * dt, axis=0)[:-1]
     if F_ext is not None:
         F_ext = np.asarray(F_ext, dtype=np.float64).reshape(-1)
         if F_ext.shape[0] != n_steps:

@@ -45,10 +45,14 @@ class EnsembleEngine:
 
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
                  device=None, store_trajectory=True, output_steps=None, collect_stats=False,
-                 R0=None, S0=None, lib_path=None):
+                 concentration_driven=False, R0=None, S0=None, lib_path=None):
         """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
         stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
-        collect_stats: also accumulate per-step ensemble moments of T on the device (`stats()`)."""
+        collect_stats: also accumulate per-step ensemble moments of T on the device (`stats()`).
+        concentration_driven: inverse mode — `emissions` holds the TARGET concentrations [n_steps, G]
+        at the end of each step (shared by all members); the per-member emissions that reach them
+        are diagnosed into `self.E` ([n_rows, G, N], aliasing `self.C`), and `self.cumE` [G, N] is
+        extra per-member state.  Runs through `run()` as one time-fused launch per call."""
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.lib = _capi.load(lib_path)    # raises if the HIP library is not built
@@ -74,7 +78,8 @@ class EnsembleEngine:
 
         if not store_trajectory:
             output_steps = []
-        drive = make_drive(emissions, F_ext, dt, output_steps)
+        self.concentration_driven = bool(concentration_driven)
+        drive = make_drive(emissions, F_ext, dt, output_steps, self.concentration_driven)
         self.out_steps = np.nonzero(drive[:, 7] >= 0)[0]          # step index of each stored row
         self.n_rows = int(self.out_steps.size)
         if drive[:, G:3].any():
@@ -92,6 +97,8 @@ class EnsembleEngine:
             self.S = torch.zeros((2, N), dtype=dt_, device=dev)
             self.C = torch.empty((self.n_rows, G, N), dtype=dt_, device=dev) if self.n_rows else None
             self.T = torch.empty((self.n_rows, N), dtype=dt_, device=dev) if self.n_rows else None
+            self.cumE = torch.zeros((G, N), dtype=dt_, device=dev) if self.concentration_driven else None
+            self.E = self.C if self.concentration_driven else None
             self.n_waves = int(self.lib.fiveeq_stats_waves(N))
             self.T_stats = (torch.zeros((self.n_steps, self.n_waves, 4), dtype=torch.float64, device=dev)
                             if collect_stats else None)
@@ -111,6 +118,8 @@ class EnsembleEngine:
             self.S.zero_()
         else:
             self.S.copy_(torch.from_numpy(self._S0).to(self.dtype))
+        if self.cumE is not None:
+            self.cumE.zero_()
 
     # -- launches ----------------------------------------------------------------------
     def _stream(self, stream=None):
@@ -126,8 +135,19 @@ class EnsembleEngine:
                 self._ptr(self.r), self._ptr(self.q), self._ptr(self.R), self._ptr(self.S),
                 self._ptr(self.C), self._ptr(self.T), self.n_rows, self._ptr(self.T_stats))
 
+    def _run_inverse(self, t_begin, t_end, stream):
+        N = self.n_members
+        fn = getattr(self.lib, f"fiveeq_run_inverse_{self._sfx}")
+        return fn(ctypes.byref(self.model), N, N, self._ptr(self.drive), self.n_steps, int(t_begin), int(t_end),
+                  self._ptr(self.r), self._ptr(self.q), self._ptr(self.R), self._ptr(self.S), self._ptr(self.cumE),
+                  self._ptr(self.C), self._ptr(self.T), self.n_rows, self._ptr(self.T_stats), self._stream(stream))
+
     def step(self, t, stream=None):
         """One timestep = one kernel launch (asynchronous)."""
+        if self.concentration_driven:
+            with torch.cuda.device(self.device):
+                _capi.check(self.lib, self._run_inverse(t, t + 1, stream))
+            return
         N = self.n_members
         fn = getattr(self.lib, f"fiveeq_step_{self._sfx}")
         with torch.cuda.device(self.device):
@@ -144,7 +164,9 @@ class EnsembleEngine:
         'fused'    one launch, state in registers across steps (bit-identical results)."""
         t_end = self.n_steps if t_end is None else int(t_end)
         with torch.cuda.device(self.device):
-            if mode == "per_step":
+            if self.concentration_driven:
+                rc = self._run_inverse(t_begin, t_end, stream)
+            elif mode == "per_step":
                 fn = getattr(self.lib, f"fiveeq_run_{self._sfx}")
                 rc = fn(*self._run_args(t_begin, t_end), self._stream(stream))
             elif mode == "fused":

@@ -164,6 +164,22 @@ int fiveeq_run_fused_f32(const fiveeq_model *model, int64_t n_members, int64_t l
                          const float *r, const float *q, float *R, float *S,
                          float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, void *stream);
 
+/* CONCENTRATION-DRIVEN (inverse) mode (the reference's module name
+ * `concentrations` hints at it, no reference code exists).  drive[t][0..2] hold the TARGET
+ * concentration of each gas at the end of step t (shared by all members; columns 3..5 unused);
+ * cumE dev [G][ld] is per-member cumulative-emission state (in/out, start at 0); the emission rate
+ * that reaches the target is diagnosed per member and step from the same pool equations and
+ * written to E_traj dev [n_rows][G][ld] (row map as above); pools, boxes, T and T_stats advance
+ * exactly as in the forward path.  One launch for the whole span (time-fused form). */
+int fiveeq_run_inverse_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                           const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                           const double *r, const double *q, double *R, double *S, double *cumE,
+                           double *E_traj, double *T_traj, int32_t n_rows, double *T_stats, void *stream);
+int fiveeq_run_inverse_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                           const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                           const float *r, const float *q, float *R, float *S, float *cumE,
+                           float *E_traj, float *T_traj, int32_t n_rows, double *T_stats, void *stream);
+
 /* Ensemble form of the reference's one function,
  *   calculate_hfc_conc(emissions, time, lifetime) = emissions[0]*exp(-time)
  * (U_FaIR/concentrations.py:4-5): out[k][m] = e0[m] * exp(-time[k]).

@@ -225,3 +225,31 @@ def test_linearity_in_emissions_when_alpha_is_frozen(s):
     a = npo.run(E, p, 1)["C"][:, 0, 0] - 278.0
     b = npo.run(s * E, p, 1)["C"][:, 0, 0] - 278.0
     np.testing.assert_allclose(b, s * a, rtol=1e-12, atol=1e-12)
+
+
+# inverse (concentration-driven) mode -------------------------------------------------------------
+def test_inverse_mode_recovers_the_emissions_of_a_forward_run():
+    """Forward run with shared emissions E; feed one member's C(t) back as the target: that member's
+    diagnosed emissions are E again (and its T is the forward T); the other members, whose carbon
+    cycle differs, need different emissions for the same pathway."""
+    N, n_steps, j = 40, 300, 17
+    p = prm.sample_ensemble(MG, N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    fwd = npo.run(E, p, N)
+    inv = npo.run_inverse(fwd["C"][:, :, j], p, N)
+    np.testing.assert_allclose(inv["E"][:, :, j], E, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(inv["T"][:, j], fwd["T"][:, j], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(inv["C"][:, :, j], fwd["C"][:, :, j], rtol=1e-13)
+    np.testing.assert_allclose(inv["C"], np.broadcast_to(fwd["C"][:, :, j:j + 1], inv["C"].shape), rtol=1e-12)
+    np.testing.assert_allclose(inv["cumE"][:, j], E.sum(0), rtol=1e-9)
+    assert np.abs(inv["E"][250, 0] - E[250, 0]).max() > 0.05          # other members differ
+
+
+def test_inverse_mode_constant_concentration_needs_decaying_emissions():
+    """Hold CO2 at 2 x C0 from a pre-industrial start: emissions spike in the first year (filling the
+    atmosphere) and then decline as the sinks saturate, staying positive."""
+    n = 200
+    inv = npo.run_inverse(np.full((n, 1), 556.0), CO2, 1)
+    e = inv["E"][:, 0, 0]
+    assert e[0] > 100 and np.all(e[1:] > 0) and np.all(np.diff(e[1:60]) < 0)
+    np.testing.assert_allclose(inv["C"][:, 0, 0], 556.0, rtol=1e-13)
