@@ -136,7 +136,38 @@ __device__ __forceinline__ double fe_rcp(double a) {
 }
 __device__ __forceinline__ float fe_rcp(float a) { return 1.0f / a; }
 
-__device__ __forceinline__ double fe_log(double x) { return log(x); }
+// ln(x) for finite normal x > 0 (a concentration ratio).  The classic fdlibm scheme:
+// x = 2^k (1+f) with sqrt(1/2) <= 1+f < sqrt(2);  s = f/(2+f);  ln(1+f) = f - f^2/2 + s (f^2/2 + R(s^2))
+// with R the degree-7 minimax polynomial in s^2 (Lg1..Lg7, |error| < 2^-58.45), and k ln2 added in
+// hi/lo parts.  The quotient uses the Newton reciprocal (2+f is in [1.7, 2.42]).  ~35 VALU ops against
+// ~95 for the general device-library routine, which carries double-double arithmetic and
+// special-case selects this argument range never needs.
+__device__ __forceinline__ double fe_log(double x) {
+#if FIVEEQ_MATH_CUSTOM
+    double m = __builtin_amdgcn_frexp_mant(x);                   // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;                                         // [sqrt(1/2), sqrt(2))
+    k = low ? k - 1 : k;
+    const double dk = (double)k;
+    const double f = m - 1.0;
+    const double s = f * fe_rcp(2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    double t1 = __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01);   // Lg6, Lg4
+    t1 = __builtin_fma(w, t1, 3.999999999940941908e-01);                                 // Lg2
+    t1 = w * t1;
+    double t2 = __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01);   // Lg7, Lg5
+    t2 = __builtin_fma(w, t2, 2.857142874366239149e-01);                                 // Lg3
+    t2 = __builtin_fma(w, t2, 6.666666666666735130e-01);                                 // Lg1
+    const double R = __builtin_fma(z, t2, t1);
+    const double hfsq = 0.5 * f * f;
+    const double tail = __builtin_fma(dk, 1.90821492927058770002e-10, s * (hfsq + R));  // + k ln2_lo
+    return __builtin_fma(dk, 6.93147180369123816490e-01, -((hfsq - tail) - f));          // k ln2_hi - ...
+#else
+    return log(x);
+#endif
+}
 __device__ __forceinline__ float fe_log(float x) { return logf(x); }
 
 // sqrt(x) for finite normal x > 0 (a concentration): v_rsq_f64 seed, two Goldschmidt steps and a
@@ -229,7 +260,7 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const T* __restrict__
     // --- step_forc (terms whose coefficient is zero are skipped: wave-uniform branch) ---
     const bool pos = Cg > T(0);
     T Fg = kg.f2 * (Cg - kg.C0);
-    if (kg.f1 != T(0)) Fg += pos ? kg.f1 * fe_log(Cg * kg.inv_C0) : T(0);
+    if (kg.f1 != T(0)) Fg += pos ? kg.f1 * fe_log(pos ? Cg * kg.inv_C0 : T(1)) : T(0);
     if (kg.f3 != T(0)) Fg += kg.f3 * ((pos ? fe_sqrt(pos ? Cg : T(1)) : T(0)) - kg.sqrtC0);
     return Fg;
 }
@@ -511,6 +542,27 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void stream_copy_kernel(const int64_t
         dst[i + 3 * stride] = v3;
     }
     for (; i < n; i += stride) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------
+// Diagnostic — evaluate one of the hand-written math primitives over an array, so that tests can
+// pin each of them against a CPU libm to the ulp, independently of the model.
+// op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0), 3 sqrt (x > 0), 4 reciprocal (x > 0).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void math_probe_kernel(const int op, const int64_t n,
+                                                                  const double* __restrict__ x, double* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    double r;
+    switch (op) {
+        case 0: r = fe_expm1_neg(v); break;
+        case 1: r = fe_exp(v); break;
+        case 2: r = fe_log(v); break;
+        case 3: r = fe_sqrt(v); break;
+        default: r = fe_rcp(v); break;
+    }
+    y[i] = r;
 }
 
 }  // namespace fiveeq

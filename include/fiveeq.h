@@ -193,6 +193,11 @@ int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time,
  * FETCH_SIZE / WRITE_SIZE counters on a known byte count (MI355X_MICROARCH.md, HBM section). */
 int fiveeq_stream_copy_f64(int64_t n, const double *src, double *dst, void *stream);
 
+/* new — diagnostic: y[i] = f(x[i]) with one of the kernels' own fp64 math primitives, so tests can
+ * pin each against a CPU libm to the ulp.  op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0, finite normal),
+ * 3 sqrt (x > 0, finite normal), 4 reciprocal (x > 0, finite normal). */
+int fiveeq_math_probe_f64(int32_t op, int64_t n, const double *x, double *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,54 @@ def _close(got, want, rtol=RTOL, atol=ATOL, what=""):
     return float(np.max(err / (np.abs(want) + 1e-300)))
 
 
+# ---- the kernels' own math primitives, to the ulp --------------------------------------------------
+def _ulp_err(got, want):
+    return np.abs(got - want) / np.spacing(np.abs(want))
+
+
+def test_device_math_primitives_within_two_ulp(gpu):
+    """Hand-written expm1 / exp / log / sqrt / reciprocal (fiveeq_device.hpp) against NumPy (glibc /
+    SVML, <= 1 ulp themselves) over the argument ranges the model can produce."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(7)
+
+    def probe(op, x):
+        xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        yd = torch.empty_like(xd)
+        _capi.check(lib, lib.fiveeq_math_probe_f64(op, xd.numel(), ctypes.c_void_p(xd.data_ptr()),
+                                                   ctypes.c_void_p(yd.data_ptr()), None))
+        torch.cuda.synchronize()
+        return yd.cpu().numpy()
+
+    n = 400_000
+    # expm1 on (-inf, 0]: log-uniform magnitudes from 1e-300 to 800 plus edge values
+    x = -np.concatenate([10.0 ** rng.uniform(-300, 2.9, n), rng.uniform(0, 2, n), [0.0, 1e-320, 0.3465, 0.3466, 0.6931,
+                                                                                      0.6932, 36.0, 37.5, 745.0, 800.0, 1e300, np.inf]])
+    got, want = probe(0, x), np.expm1(x)
+    assert np.all(got[x == 0] == 0) and got[-1] == -1.0 and got[-2] == -1.0
+    assert _ulp_err(got, want).max() <= 2.0, _ulp_err(got, want).max()
+    small = np.abs(x) < 1e-5                                           # the tau = 1e6 yr pool: full RELATIVE accuracy
+    assert np.max(np.abs(got[small] - want[small]) / np.maximum(np.abs(want[small]), 1e-320)) < 3e-16
+    # exp on [-700, 700] (clamped outside)
+    x = np.concatenate([rng.uniform(-700, 700, n), rng.uniform(-12, 12, n), [0.0, -700.0, 700.0]])
+    assert _ulp_err(probe(1, x), np.exp(x)).max() <= 2.0
+    assert probe(1, np.array([1e4, -1e4])).tolist() == [float(np.exp(700.0)), float(np.exp(-700.0))]
+    # log, sqrt, reciprocal on positive normals
+    x = np.concatenate([10.0 ** rng.uniform(-280, 280, n), rng.uniform(0.5, 4.0, n), [1.0, 0.5, 2.0, 0.7071067811865475,
+                                                                                       0.7071067811865476, 1.4142135623730951]])
+    got, want = probe(2, x), np.log(x)
+    assert probe(2, np.array([1.0]))[0] == 0.0
+    nz = want != 0
+    assert _ulp_err(got[nz], want[nz]).max() <= 2.0, _ulp_err(got[nz], want[nz]).max()
+    near1 = np.concatenate([rng.uniform(0.999, 1.001, n), 1.0 + 10.0 ** rng.uniform(-15, -3, 1000)])
+    got, want = probe(2, near1), np.log(near1)                         # ln near 1 keeps RELATIVE accuracy
+    nz = want != 0
+    assert _ulp_err(got[nz], want[nz]).max() <= 2.0
+    assert _ulp_err(probe(3, x), np.sqrt(x)).max() <= 1.0
+    assert _ulp_err(probe(4, x), 1.0 / x).max() <= 1.0
+
+
 # ---- the reference's function, ensemble form ---------------------------------------------------
 def test_hfc_conc_kernel_matches_reference_golden(gpu, golden_hfc):
     from fiveeqscm_amd.concentrations import calculate_hfc_conc_ensemble
