@@ -143,12 +143,19 @@ def main():
             sys.exit(f"--gpus {a.gpus} needs the torch.distributed.run launcher (see the docstring)")
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # FIVEEQ_BENCH_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks
+    # (ranks share devices, the summary exchange goes through host memory); the default is RCCL.
+    backend = os.environ.get("FIVEEQ_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)        # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)    # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from fiveeqscm_amd import emissions, params
     from fiveeqscm_amd.distributed import gather_summary, shard_bounds
@@ -191,7 +198,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = n_total * a.steps / elapsed
@@ -258,7 +265,8 @@ def main():
     if eng.T is not None:
         torch.cuda.synchronize(dev)
         ts = time.perf_counter()
-        years = [t for t in (249, 499, 749) if t < n_scen]
+        done = min(a.warmup + a.steps, n_scen)                  # scenario steps the timed run has written
+        years = [t for t in (249, 499, 749) if t < done] or [done - 1]
         summary = gather_summary(eng.T[years], percentiles=(5.0, 50.0, 95.0))
         torch.cuda.synchronize(dev)
         summary_ms = (time.perf_counter() - ts) * 1e3
@@ -271,6 +279,7 @@ def main():
         "config": {"workload": f"{a.workload}: {desc}", "members_per_gpu": per_gpu, "members_total": n_total,
                    "gases": G, "pools": eng.pools, "scenario_steps": n_scen, "mode": a.mode,
                    "trajectory_stored": eng.C is not None, "parallelism": f"member-shard x{world}",
+                   "collective_backend": "rccl" if backend == "nccl" else backend,
                    "emissions_sha256": emissions.emissions_sha256(E)[:16], "lhs_seed": params.LHS_SEED},
         "roofline": roofline,
     }

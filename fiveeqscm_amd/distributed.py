@@ -30,6 +30,14 @@ def _dist(group):
     return None, 0, 1
 
 
+def _comm_tensor(dist, group, x):
+    """Collectives run where the backend can reach: device tensors over RCCL ("nccl"), host copies
+    over gloo (CPU tests, and single-GPU rehearsals of the multi-process path)."""
+    if dist is not None and dist.get_backend(group) == "gloo" and x.is_cuda:
+        return x.cpu()
+    return x
+
+
 def local_moments(x):
     """x [K, n] -> [K, 5] = (count, mean, M2, min, max) per row, in fp64."""
     x = x.to(torch.float64)
@@ -80,7 +88,7 @@ def reduce_stats(sums, group=None):
     (three tiny collectives: SUM on the first three columns, MIN, MAX) and return the ensemble
     moments on every rank.  This is all a run without stored trajectories has to exchange."""
     dist, _, world = _dist(group)
-    sums = sums.clone()
+    sums = _comm_tensor(dist, group, sums).clone()
     if world > 1:
         add, mn, mx = sums[:, :3].contiguous(), sums[:, 3].contiguous(), sums[:, 4].contiguous()
         dist.all_reduce(add, op=dist.ReduceOp.SUM, group=group)
@@ -95,7 +103,7 @@ def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None):
     Returns on every rank a dict with the merged moments (mean, var, min, max, count; [K] each, fp64);
     on rank `dst` it also holds 'percentiles' [K, len(percentiles)] over ALL members (None elsewhere)."""
     dist, rank, world = _dist(group)
-    rows = rows.contiguous()
+    rows = _comm_tensor(dist, group, rows.contiguous())
     K, n_local = rows.shape
     mom = local_moments(rows)
     if world > 1:
