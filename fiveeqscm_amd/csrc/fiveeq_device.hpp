@@ -374,32 +374,48 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
     const int n_rows, double* __restrict__ stats /* [n_steps][n_waves][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[DRIVE_STRIDE];
+    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
+    const bool active = m < n;
+    const int64_t mm = active ? m : n - 1;      // idle tail lanes load a valid member and store nothing
 #if FIVEEQ_MODEL_LDS
+    // Issue order matters for the workgroup's critical path: first the (tiny) shared loads, then
+    // all 19 row loads, and only then the LDS writes + barrier, so the staging round trip is
+    // overlapped with the row round trip instead of preceding it (+1.3 % at 1M members, neutral
+    // elsewhere: profiles/r01/ab_variants.txt).
     __shared__ KModel<T> km_s;
-    stage_model(&km_s);
+    constexpr int NW = sizeof(KModel<T>) / sizeof(T);
+    static_assert(NW <= FIVEEQ_BLOCK, "model must stage in one pass");
+    const T* kargs = (const T*)__builtin_amdgcn_kernarg_segment_ptr();
+    T stage_v = T(0), drv_v = T(0);
+    if (threadIdx.x < NW) stage_v = kargs[threadIdx.x];
+    if (threadIdx.x < DRIVE_STRIDE) drv_v = drive[(int64_t)t * DRIVE_STRIDE + threadIdx.x];
     const KModel<T>& kmr = km_s;
 #else
     const KModel<T>& kmr = km;
-#endif
     if (threadIdx.x < DRIVE_STRIDE) drv[threadIdx.x] = drive[(int64_t)t * DRIVE_STRIDE + threadIdx.x];
     __syncthreads();
+#endif
 
-    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
-    const bool active = m < n;
+    T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G];
+#pragma unroll
+    for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
+
+#if FIVEEQ_MODEL_LDS
+    if (threadIdx.x < NW) reinterpret_cast<T*>(&km_s)[threadIdx.x] = stage_v;
+    if (threadIdx.x < DRIVE_STRIDE) drv[threadIdx.x] = drv_v;
+    __syncthreads();
+#endif
+
     T Tn = T(0);
-    if (active) {
-        T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G];
-#pragma unroll
-        for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + m];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + m];
-#pragma unroll
-        for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + m];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + m];
-
+    {
         member_step<T, L>(kmr, drv, rr, qq, Rv, Sv, Cv, Tn);
-
+        if (active) {
 #pragma unroll
         for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
 #pragma unroll
@@ -411,6 +427,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
                 for (int g = 0; g < L::G; ++g) store_stream(&C_traj[(row * L::G + g) * ld + m], Cv[g]);
             }
             if (T_traj != nullptr) store_stream(&T_traj[row * ld + m], Tn);
+        }
         }
     }
     if (stats != nullptr) {
