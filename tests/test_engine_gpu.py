@@ -520,3 +520,36 @@ def test_full_size_config3_properties(gpu):
     eng.run(mode="fused")
     torch.cuda.synchronize()
     assert torch.equal(eng.T, Tp) and torch.equal(eng.C[-1], Cp)
+
+
+def test_full_size_config5_shard_fp32_sparse_outputs(gpu):
+    """BASELINE configs[4]: one GPU's shard of the 100M-member fp32 ensemble (12.5M members), run the way
+    such a job must be run: time-fused, three stored years instead of a 150 GB trajectory, per-step
+    moments on the device.  Size-independent checks: the ensemble is a 4096-member block tiled 3052x,
+    so every stored row is periodic with period 4096 bit for bit; tile 0 tracks the fp64 oracle within
+    the fp32 budget; the on-device moments equal the moments of the stored rows."""
+    N, B, n_steps = 12_500_000, 4096, 750
+    blk = prm.sample_ensemble(prm.default_params("multigas"), B)
+    p = dict(blk)
+    reps = -(-N // B)
+    for k in ("r0", "rC", "rT", "q"):
+        p[k] = np.tile(blk[k].astype(np.float32), (1, reps))[:, :N]
+    E = emi.rcp_like_emissions(n_steps, 3)
+    years = [249, 499, 749]
+    eng = _engine(p, N, E, dtype=torch.float32, output_steps=years, collect_stats=True)
+    eng.run(mode="fused")
+    torch.cuda.synchronize()
+    assert eng.T.shape == (3, N) and eng.C.shape == (3, 3, N)
+    want = c_oracle.run(E, blk, B, n_threads=8)
+    _close(eng.T[:, :B].double(), want["T"][years], rtol=1e-4, atol=1e-5, what="T tile0 fp32")
+    _close(eng.C[:, :, :B].double(), want["C"][years], rtol=1e-4, atol=1e-4, what="C tile0 fp32")
+    full = (N // B) * B
+    Tt = eng.T[:, :full].view(3, N // B, B)
+    assert torch.equal(Tt, Tt[:, :1, :].expand_as(Tt))
+    assert torch.equal(eng.T[:, full:], eng.T[:, :N - full])
+    st = eng.stats()
+    for row, t in enumerate(years):
+        x = eng.T[row].double()
+        assert abs(st["mean"][t].item() - x.mean().item()) <= 1e-12 * abs(x.mean().item())
+        assert st["min"][t].item() == x.min().item() and st["max"][t].item() == x.max().item()
+    assert st["count"][0].item() == float(N)
