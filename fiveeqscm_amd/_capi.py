@@ -87,6 +87,7 @@ SIGNATURES = {
     "fiveeq_hfc_conc_f64": (ctypes.c_int, [_i64, _i64, _i32, _p, _p, _p, _p]),
     "fiveeq_stream_copy_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
     "fiveeq_math_probe_f64": (ctypes.c_int, [_i32, _i64, _p, _p, _p]),
+    "fiveeq_math_probe_f32": (ctypes.c_int, [_i32, _i64, _p, _p, _p]),
 }
 
 _lib = None

@@ -411,16 +411,29 @@ int fiveeq_stream_copy_f64(int64_t n, const double* src, double* dst, void* stre
     return FIVEEQ_OK;
 }
 
-int fiveeq_math_probe_f64(int32_t op, int64_t n, const double* x, double* y, void* stream) {
+}  // extern "C"
+
+namespace {
+template <typename T>
+int math_probe(int32_t op, int64_t n, const T* x, T* y, void* stream) {
     if (op < 0 || op > 4) return fail(FIVEEQ_E_INVALID, "op=%d outside 0..4", op);
     if (n < 1) return fail(FIVEEQ_E_INVALID, "n=%lld must be >= 1", (long long)n);
     if (!x || !y) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
     const int64_t blocks = member_blocks(n);
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n too large");
-    hipLaunchKernelGGL(fiveeq::math_probe_kernel, dim3((unsigned)blocks), dim3(FIVEEQ_BLOCK), 0, (hipStream_t)stream, op,
-                       n, x, y);
+    hipLaunchKernelGGL(fiveeq::math_probe_kernel<T>, dim3((unsigned)blocks), dim3(FIVEEQ_BLOCK), 0, (hipStream_t)stream,
+                       op, n, x, y);
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;
+}
+}  // namespace
+
+extern "C" {
+int fiveeq_math_probe_f64(int32_t op, int64_t n, const double* x, double* y, void* stream) {
+    return math_probe<double>(op, n, x, y, stream);
+}
+int fiveeq_math_probe_f32(int32_t op, int64_t n, const float* x, float* y, void* stream) {
+    return math_probe<float>(op, n, x, y, stream);
 }
 
 }  // extern "C"

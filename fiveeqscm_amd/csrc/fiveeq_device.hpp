@@ -105,7 +105,33 @@ __device__ __forceinline__ double fe_expm1_neg(double x) {
     return expm1(x);
 #endif
 }
-__device__ __forceinline__ float fe_expm1_neg(float x) { return expm1f(x); }
+// fp32 twins of the routines above (same structure, float constants): Cody-Waite ln2 split with 12
+// zero low bits in the high part, degree-7 Taylor of expm1(r) (truncation 1.5e-8 relative).
+__device__ __forceinline__ float fe_expm1_reduced(float r) {
+    float q = 1.0f / 5040.0f;
+    q = __builtin_fmaf(q, r, 1.0f / 720.0f);
+    q = __builtin_fmaf(q, r, 1.0f / 120.0f);
+    q = __builtin_fmaf(q, r, 1.0f / 24.0f);
+    q = __builtin_fmaf(q, r, 1.0f / 6.0f);
+    q = __builtin_fmaf(q, r, 0.5f);
+    return __builtin_fmaf(r * r, q, r);
+}
+__device__ __forceinline__ float fe_reduce_ln2(float x, float& k) {
+    k = __builtin_rintf(x * 1.44269504088896341f);
+    const float r = __builtin_fmaf(-k, 0.693145751953125f, x);
+    return __builtin_fmaf(-k, 1.42860682030941723212e-6f, r);
+}
+__device__ __forceinline__ float fe_expm1_neg(float x) {
+#if FIVEEQ_MATH_CUSTOM
+    x = fmaxf(x, -100.0f);                                   // expf(-100) == 0: result -1
+    float k;
+    const float p = fe_expm1_reduced(fe_reduce_ln2(x, k));
+    const float s = __builtin_ldexpf(1.0f, (int)k);
+    return __builtin_fmaf(s, p, s - 1.0f);
+#else
+    return expm1f(x);
+#endif
+}
 
 // exp(x) for the alpha closure.  The argument is clamped to +-700 so that alpha is always a
 // finite normal number (e^+-700 ~ 1e+-304) and the Newton reciprocal below is always valid.
@@ -119,7 +145,16 @@ __device__ __forceinline__ double fe_exp(double x) {
     return exp(x);
 #endif
 }
-__device__ __forceinline__ float fe_exp(float x) { return expf(fminf(fmaxf(x, -80.0f), 80.0f)); }
+__device__ __forceinline__ float fe_exp(float x) {
+    x = fminf(fmaxf(x, -80.0f), 80.0f);                      // alpha stays a finite normal float
+#if FIVEEQ_MATH_CUSTOM
+    float k;
+    const float p = fe_expm1_reduced(fe_reduce_ln2(x, k));
+    return __builtin_ldexpf(1.0f + p, (int)k);
+#else
+    return expf(x);
+#endif
+}
 
 // 1/a for finite normal a > 0 (alpha): v_rcp_f64 seed + two Newton steps (<= 1 ulp), without the
 // scale / fixup sequence a full IEEE division needs for subnormal and infinite operands.
@@ -134,7 +169,14 @@ __device__ __forceinline__ double fe_rcp(double a) {
     return 1.0 / a;
 #endif
 }
-__device__ __forceinline__ float fe_rcp(float a) { return 1.0f / a; }
+__device__ __forceinline__ float fe_rcp(float a) {
+#if FIVEEQ_MATH_CUSTOM
+    const float y = __builtin_amdgcn_rcpf(a);                // v_rcp_f32 (1 ulp) + one Newton step
+    return __builtin_fmaf(y, __builtin_fmaf(-a, y, 1.0f), y);
+#else
+    return 1.0f / a;
+#endif
+}
 
 // ln(x) for finite normal x > 0 (a concentration ratio).  The classic fdlibm scheme:
 // x = 2^k (1+f) with sqrt(1/2) <= 1+f < sqrt(2);  s = f/(2+f);  ln(1+f) = f - f^2/2 + s (f^2/2 + R(s^2))
@@ -168,7 +210,28 @@ __device__ __forceinline__ double fe_log(double x) {
     return log(x);
 #endif
 }
-__device__ __forceinline__ float fe_log(float x) { return logf(x); }
+__device__ __forceinline__ float fe_log(float x) {
+#if FIVEEQ_MATH_CUSTOM
+    float m = __builtin_amdgcn_frexp_mantf(x);
+    int k = __builtin_amdgcn_frexp_expf(x);
+    const bool low = m < 0.70710678118654752440f;
+    m = low ? m + m : m;
+    k = low ? k - 1 : k;
+    const float dk = (float)k;
+    const float f = m - 1.0f;
+    const float s = f * fe_rcp(2.0f + f);
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * __builtin_fmaf(w, 0.24279078841f, 0.40000972152f);               // Lg4, Lg2
+    const float t2 = z * __builtin_fmaf(w, 0.28498786688f, 0.66666662693f);               // Lg3, Lg1
+    const float R = t2 + t1;
+    const float hfsq = 0.5f * f * f;
+    const float tail = __builtin_fmaf(dk, 9.0580006145e-06f, s * (hfsq + R));             // + k ln2_lo
+    return __builtin_fmaf(dk, 6.9313812256e-01f, -((hfsq - tail) - f));                    // k ln2_hi - ...
+#else
+    return logf(x);
+#endif
+}
 
 // sqrt(x) for finite normal x > 0 (a concentration): v_rsq_f64 seed, two Goldschmidt steps and a
 // final residual correction (<= 1 ulp), without the rescaling a full sqrt needs near the ends
@@ -190,7 +253,13 @@ __device__ __forceinline__ double fe_sqrt(double x) {
     return sqrt(x);
 #endif
 }
-__device__ __forceinline__ float fe_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float fe_sqrt(float x) {
+#if FIVEEQ_MATH_CUSTOM
+    return __builtin_amdgcn_sqrtf(x);                        // v_sqrt_f32: 1 ulp for normal x > 0
+#else
+    return sqrtf(x);
+#endif
+}
 __device__ __forceinline__ double fe_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ float fe_min(float a, float b) { return fminf(a, b); }
 
@@ -566,12 +635,13 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void stream_copy_kernel(const int64_t
 // pin each of them against a CPU libm to the ulp, independently of the model.
 // op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0), 3 sqrt (x > 0), 4 reciprocal (x > 0).
 // ---------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void math_probe_kernel(const int op, const int64_t n,
-                                                                  const double* __restrict__ x, double* __restrict__ y) {
+                                                                  const T* __restrict__ x, T* __restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const double v = x[i];
-    double r;
+    const T v = x[i];
+    T r;
     switch (op) {
         case 0: r = fe_expm1_neg(v); break;
         case 1: r = fe_exp(v); break;

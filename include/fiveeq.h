@@ -197,6 +197,7 @@ int fiveeq_stream_copy_f64(int64_t n, const double *src, double *dst, void *stre
  * pin each against a CPU libm to the ulp.  op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0, finite normal),
  * 3 sqrt (x > 0, finite normal), 4 reciprocal (x > 0, finite normal). */
 int fiveeq_math_probe_f64(int32_t op, int64_t n, const double *x, double *y, void *stream);
+int fiveeq_math_probe_f32(int32_t op, int64_t n, const float *x, float *y, void *stream);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,41 @@ def test_device_math_primitives_within_two_ulp(gpu):
     assert _ulp_err(probe(4, x), 1.0 / x).max() <= 1.0
 
 
+def test_device_math_primitives_fp32(gpu):
+    """The fp32 twins against fp64 NumPy rounded to float: <= 2 ulp (float)."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(8)
+
+    def probe(op, x):
+        xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+        yd = torch.empty_like(xd)
+        _capi.check(lib, lib.fiveeq_math_probe_f32(op, xd.numel(), ctypes.c_void_p(xd.data_ptr()),
+                                                   ctypes.c_void_p(yd.data_ptr()), None))
+        torch.cuda.synchronize()
+        return yd.cpu().numpy(), xd.cpu().numpy().astype(np.float64)
+
+    def ulp32(got, want64):
+        w = want64.astype(np.float32)
+        return np.abs(got.astype(np.float64) - want64) / np.spacing(np.abs(w)).astype(np.float64)
+
+    n = 200_000
+    x = -np.concatenate([10.0 ** rng.uniform(-30, 1.9, n), rng.uniform(0, 2, n), [0.0, 0.3466, 0.6932, 17.0, 87.0, 100.0, 1e30]])
+    got, xx = probe(0, x)
+    assert ulp32(got, np.expm1(xx)).max() <= 2.0 and got[-1] == -1.0
+    x = np.concatenate([rng.uniform(-80, 80, n), rng.uniform(-12, 12, n)])
+    got, xx = probe(1, x)
+    assert ulp32(got, np.exp(xx)).max() <= 2.0
+    x = np.concatenate([10.0 ** rng.uniform(-30, 30, n), rng.uniform(0.5, 4.0, n), 1.0 + 10.0 ** rng.uniform(-6, -2, 1000)])
+    got, xx = probe(2, x)
+    nz = np.log(xx) != 0
+    assert ulp32(got[nz], np.log(xx)[nz]).max() <= 2.0
+    got, xx = probe(3, x)
+    assert ulp32(got, np.sqrt(xx)).max() <= 1.0
+    got, xx = probe(4, x)
+    assert ulp32(got, 1.0 / xx).max() <= 1.0
+
+
 # ---- the reference's function, ensemble form ---------------------------------------------------
 def test_hfc_conc_kernel_matches_reference_golden(gpu, golden_hfc):
     from fiveeqscm_amd.concentrations import calculate_hfc_conc_ensemble
