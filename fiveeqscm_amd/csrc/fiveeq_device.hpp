@@ -425,6 +425,55 @@ __device__ __forceinline__ void wave_stats(const bool active, const T Tn, double
 }
 
 // ---------------------------------------------------------------------------------
+// The time-fused kernel produces one T per lane EVERY step, so it batches the statistics instead
+// of running the DPP ladder per step (which costs +20 % fp64 / +70 % fp32 there): each wave parks
+// its T values in a wave-private LDS tile [STAT_STEPS][64 (+1 pad)], and every STAT_STEPS steps
+// the tile is reduced TRANSPOSED: lane l owns step j = l % 8 and the eighth p = l / 8 of that
+// step's 64 members, folds its 8 values serially in fp64, and the 8 partials per step are combined
+// with three xor-shuffles (8, 16, 32).  Row stride 65 elements makes both the row writes and the
+// strided reads bank-conflict-free (bank = j + 8 p + i mod 32).  A wave's LDS operations complete
+// in program order, so only compiler (wavefront-scope) fences are needed, no barrier.
+// ---------------------------------------------------------------------------------
+constexpr int STAT_STEPS = 8;
+constexpr int STAT_ROW = 65;
+
+template <typename T>
+__device__ __forceinline__ void wave_stats_flush(const T* tile /* [STAT_STEPS][STAT_ROW] */, const int count,
+                                                 const int n_valid, double* __restrict__ out, const int64_t stride) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (STAT_STEPS - 1), p = lane >> 3;
+    const double inf = __builtin_inf();
+    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = p * 8 + i;
+        const double v = (double)tile[j * STAT_ROW + idx];
+        if (idx < n_valid) {
+            s1 += v;
+            s2 = __builtin_fma(v, v, s2);
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+    }
+#pragma unroll
+    for (int sh = 8; sh < 64; sh <<= 1) {
+        s1 += __shfl_xor(s1, sh);
+        s2 += __shfl_xor(s2, sh);
+        mn = fmin(mn, __shfl_xor(mn, sh));
+        mx = fmax(mx, __shfl_xor(mx, sh));
+    }
+    if (p == 0 && j < count) {
+        double* o = out + (int64_t)j * stride;
+        o[0] = s1;
+        o[1] = s2;
+        o[2] = mn;
+        o[3] = mx;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------
 // Kernel 1 — ONE TIMESTEP PER LAUNCH (the north-star form).
 // Per member-step HBM traffic (elements): read SP + 2 (state) + 3G + 2 (params),
 // write SP + 2 (state) + G + 1 (C, T rows)  ->  A = w (2 SP + 4 G + 7) bytes
@@ -526,6 +575,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const int n_rows, double* __restrict__ stats /* [n_steps][n_waves][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
+    __shared__ T stat_tile[FIVEEQ_BLOCK / 64][STAT_STEPS * STAT_ROW];
 #if FIVEEQ_MODEL_LDS
     __shared__ KModel<T> km_s;
     stage_model(&km_s);
@@ -540,6 +590,9 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const int64_t n_waves = (n + 63) >> 6;
     const int64_t wave = (int64_t)blockIdx.x * (FIVEEQ_BLOCK / 64) + (threadIdx.x >> 6);
     const bool wave_live = stats != nullptr && wave < n_waves;
+    T* const tile = stat_tile[threadIdx.x >> 6];
+    const int n_valid = (int)min((int64_t)64, n - wave * 64);      // members of this wave (<= 0: none)
+    int ks = 0;                                                      // steps parked in the tile
 
     T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
     if constexpr (INV) {
@@ -572,8 +625,14 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
                 }
                 if (T_traj != nullptr) store_stream(&T_traj[row * ld + m], Tn);
             }
-            if (wave_live)
-                wave_stats(active, Tn, stats + ((int64_t)(tc + k) * n_waves + wave) * 4);
+            if (wave_live) {
+                tile[ks * STAT_ROW + (threadIdx.x & 63)] = Tn;
+                if (++ks == STAT_STEPS || tc + k + 1 == t_end) {
+                    const int64_t t_first = (int64_t)(tc + k + 1 - ks);
+                    wave_stats_flush(tile, ks, n_valid, stats + (t_first * n_waves + wave) * 4, n_waves * 4);
+                    ks = 0;
+                }
+            }
         }
     }
     if (active) {
