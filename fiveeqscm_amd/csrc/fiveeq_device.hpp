@@ -19,8 +19,8 @@
 #define FIVEEQ_MATH_CUSTOM 1      // 1: hand-written range-restricted expm1 (fp64); 0: ocml
 #endif
 #ifndef FIVEEQ_NT_STORE
-#define FIVEEQ_NT_STORE 1         // trajectory rows are write-once: non-temporal stores
-#endif
+#define FIVEEQ_NT_STORE 0         // 1: non-temporal stores for the write-once trajectory rows.  Measured:
+#endif                            // no gain at 1M members, 4 % slower at 8M (profiles/r01/ab_variants.txt)
 #ifndef FIVEEQ_MODEL_LDS
 #define FIVEEQ_MODEL_LDS 1        // 1: shared model constants staged in LDS; 0: kernarg -> SGPRs
 #endif
