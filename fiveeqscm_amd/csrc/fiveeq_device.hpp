@@ -538,13 +538,14 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
         for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
 #pragma unroll
         for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
-        const int64_t row = (int64_t)drv[7];
+        const int row = __builtin_amdgcn_readfirstlane((int)drv[7]);     // wave-uniform: scalar test + offsets
         if (row >= 0 && row < n_rows) {
             if (C_traj != nullptr) {
+                T* c = C_traj + (int64_t)row * L::G * ld + m;
 #pragma unroll
-                for (int g = 0; g < L::G; ++g) store_stream(&C_traj[(row * L::G + g) * ld + m], Cv[g]);
+                for (int g = 0; g < L::G; ++g) store_stream(c + g * ld, Cv[g]);
             }
-            if (T_traj != nullptr) store_stream(&T_traj[row * ld + m], Tn);
+            if (T_traj != nullptr) store_stream(T_traj + (int64_t)row * ld + m, Tn);
         }
         }
     }
@@ -617,13 +618,18 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
         for (int k = 0; k < nt; ++k) {
             const T* d = &drv[k * DRIVE_STRIDE];
             member_step<T, L, INV>(kmr, d, rr, qq, Rv, Sv, Cv, Tn, cum);
-            const int64_t row = (int64_t)d[7];
-            if (active && row >= 0 && row < n_rows) {
-                if (C_traj != nullptr) {
+            // the output row is wave-uniform: read it once into an SGPR so that the row test is a
+            // scalar branch and the row offsets are scalar arithmetic, not 64-bit VALU per lane
+            const int row = __builtin_amdgcn_readfirstlane((int)d[7]);
+            if (row >= 0 && row < n_rows) {
+                if (active) {
+                    if (C_traj != nullptr) {
+                        T* c = C_traj + (int64_t)row * L::G * ld + m;
 #pragma unroll
-                    for (int g = 0; g < L::G; ++g) store_stream(&C_traj[(row * L::G + g) * ld + m], Cv[g]);
+                        for (int g = 0; g < L::G; ++g) store_stream(c + g * ld, Cv[g]);
+                    }
+                    if (T_traj != nullptr) store_stream(T_traj + (int64_t)row * ld + m, Tn);
                 }
-                if (T_traj != nullptr) store_stream(&T_traj[row * ld + m], Tn);
             }
             if (wave_live) {
                 tile[ks * STAT_ROW + (threadIdx.x & 63)] = Tn;

@@ -310,6 +310,51 @@ def test_all_compiled_layouts_match_oracle(gpu):
             _close(eng.T, want["T"], what=f"T {pools} {mode}")
 
 
+def test_random_models_and_scenarios_match_oracle(gpu):
+    """30 randomly drawn models (pool fractions and time-scales, feedback strengths, forcing
+    coefficients, box time-scales, dt) x random emission series with spikes and negative spells,
+    every compiled gas count: per-step and fused paths against the NumPy oracle at 1e-10."""
+    rng = np.random.default_rng(2026)
+    worst = 0.0
+    for case in range(30):
+        G = int(rng.integers(1, 4))
+        pools = [int(rng.choice([1, 4])) for _ in range(G)]
+        if tuple(pools) not in {(1,), (4,), (1, 1), (4, 1), (4, 4), (1, 1, 1), (4, 1, 1), (4, 4, 1), (4, 4, 4)}:
+            pools = sorted(pools, reverse=True)
+        a = np.zeros((G, 4))
+        tau = np.ones((G, 4))
+        for g, P in enumerate(pools):
+            w = rng.uniform(0.1, 1.0, size=P)
+            a[g, :P] = w / w.sum()
+            tau[g, :P] = np.sort(10.0 ** rng.uniform(0.3, 5.5, size=P))[::-1] if P > 1 else 10.0 ** rng.uniform(0.5, 2.3)
+        N = int(rng.integers(1, 700))
+        n_steps = int(rng.integers(5, 260))
+        dt = float(rng.choice([0.25, 0.5, 1.0, 2.0]))
+        base = {"a": a, "tau": tau, "r0": rng.uniform(8, 60, G), "rC": rng.uniform(0, 0.03, G),
+                "rT": rng.uniform(-1, 5, G), "ra": rng.uniform(0, 5e-4, G), "PI_conc": rng.uniform(100, 800, G),
+                "emis2conc": rng.uniform(0.1, 0.6, G), "f": rng.uniform(0, 1, (G, 3)) * np.array([5.0, 0.01, 0.1]),
+                "iirf_max": float(rng.uniform(60, 110)), "d": np.array([rng.uniform(100, 400), rng.uniform(1, 9)]),
+                "q": rng.uniform(0.1, 0.6, 2)}
+        p = prm.sample_ensemble(base, N, seed=case)
+        E = rng.normal(0, 1, (n_steps, G)).cumsum(0) * rng.uniform(0.1, 3.0, G) + rng.uniform(0, 8, G)
+        E[rng.integers(0, n_steps, 3)] *= 6.0                          # spikes
+        F_ext = rng.normal(0, 0.3, n_steps)
+        want = npo.run(E, p, N, F_ext=F_ext, dt=dt)
+        if not (np.all(np.isfinite(want["C"])) and np.all(np.isfinite(want["T"]))):
+            continue                                                   # a draw the model itself cannot digest
+        for mode in ("per_step", "fused"):
+            eng = _engine(p, N, E, F_ext=F_ext, dt=dt)
+            eng.run(mode=mode)
+            torch.cuda.synchronize()
+            scale = np.maximum(np.abs(want["C"]), np.abs(want["C"] - np.asarray(base["PI_conc"])[None, :, None]).max())
+            errC = np.abs(eng.C.cpu().numpy() - want["C"]) / (RTOL * scale + ATOL)
+            errT = np.abs(eng.T.cpu().numpy() - want["T"]) / (RTOL * np.maximum(np.abs(want["T"]), np.abs(want["T"]).max())
+                                                                + ATOL)
+            worst = max(worst, float(errC.max()), float(errT.max()))
+            assert errC.max() <= 1.0 and errT.max() <= 1.0, (case, mode, pools, float(errC.max()), float(errT.max()))
+    assert worst > 0.0
+
+
 def test_external_forcing_and_substeps(gpu):
     N, n_steps, dt = 500, 300, 0.25
     p = prm.sample_ensemble(prm.default_params("co2"), N)
