@@ -415,6 +415,26 @@ int fiveeq_stream_copy_f64(int64_t n, const double* src, double* dst, void* stre
 
 namespace {
 template <typename T>
+int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, double hi, int32_t n_bins,
+              uint64_t* hist, void* stream) {
+    if (n_rows < 0) return fail(FIVEEQ_E_INVALID, "n_rows=%d must be >= 0", n_rows);
+    if (n < 1 || ld < n) return fail(FIVEEQ_E_INVALID, "n_members=%lld, ld=%lld invalid", (long long)n, (long long)ld);
+    if (n_bins < 1 || n_bins > fiveeq::HIST_MAX_BINS)
+        return fail(FIVEEQ_E_INVALID, "n_bins=%d outside 1..%d", n_bins, fiveeq::HIST_MAX_BINS);
+    if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) return fail(FIVEEQ_E_INVALID, "need finite lo < hi");
+    if (n_rows == 0) return FIVEEQ_OK;
+    if (!rows || !hist) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    if (n_rows > 65535) return fail(FIVEEQ_E_INVALID, "n_rows=%d exceeds the 65535 rows of one launch", n_rows);
+    const int64_t chunks = (n + fiveeq::HIST_CHUNK - 1) / fiveeq::HIST_CHUNK;
+    if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
+    hipLaunchKernelGGL(fiveeq::hist_rows_kernel<T>, dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
+                       (hipStream_t)stream, n, ld, rows, lo, (double)n_bins / (hi - lo), n_bins,
+                       reinterpret_cast<unsigned long long*>(hist));
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
+template <typename T>
 int math_probe(int32_t op, int64_t n, const T* x, T* y, void* stream) {
     if (op < 0 || op > 4) return fail(FIVEEQ_E_INVALID, "op=%d outside 0..4", op);
     if (n < 1) return fail(FIVEEQ_E_INVALID, "n=%lld must be >= 1", (long long)n);
@@ -429,6 +449,14 @@ int math_probe(int32_t op, int64_t n, const T* x, T* y, void* stream) {
 }  // namespace
 
 extern "C" {
+int fiveeq_hist_rows_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, double lo, double hi,
+                         int32_t n_bins, uint64_t* hist, void* stream) {
+    return hist_rows<double>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, stream);
+}
+int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, double lo, double hi,
+                         int32_t n_bins, uint64_t* hist, void* stream) {
+    return hist_rows<float>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, stream);
+}
 int fiveeq_math_probe_f64(int32_t op, int64_t n, const double* x, double* y, void* stream) {
     return math_probe<double>(op, n, x, y, stream);
 }

@@ -677,6 +677,44 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hfc_conc_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// Kernel 4 — fixed-bin histograms of stored rows (all-timestep percentiles).
+// hist[row][bin] += #members with lo + bin*w <= x < lo + (bin+1)*w ; values outside [lo, hi) go to
+// the edge bins, NaNs are skipped.  One workgroup = one row x one chunk of HIST_CHUNK members:
+// privatised LDS histogram (ds_add_u32), then only the non-zero bins are added to the global
+// 64-bit counters.  Reads each stored value once: 8 (4) B per member and row.
+// ---------------------------------------------------------------------------------
+constexpr int HIST_CHUNK = 16384;
+constexpr int HIST_MAX_BINS = 4096;
+
+template <typename T>
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n, const int64_t ld,
+                                                                 const T* __restrict__ rows, const double lo,
+                                                                 const double inv_w, const int n_bins,
+                                                                 unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int h[HIST_MAX_BINS];
+    for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) h[b] = 0u;
+    __syncthreads();
+    const int64_t row = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * HIST_CHUNK;
+    const int64_t m1 = min(m0 + HIST_CHUNK, n);
+    const T* x = rows + row * ld;
+    for (int64_t m = m0 + threadIdx.x; m < m1; m += FIVEEQ_BLOCK) {
+        const double v = (double)x[m];
+        if (v == v) {
+            const double pos = (v - lo) * inv_w;
+            const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
+            atomicAdd(&h[b], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned long long* out = hist + row * n_bins;
+    for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) {
+        const unsigned int c = h[b];
+        if (c) atomicAdd(&out[b], (unsigned long long)c);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Diagnostic — STREAM copy with the step kernel's access shape (8 B per lane), used to
 // measure achievable bandwidth and to calibrate the FETCH_SIZE / WRITE_SIZE counters.
 // ---------------------------------------------------------------------------------

@@ -220,6 +220,23 @@ class EnsembleEngine:
         from .distributed import moments_from_sums
         return moments_from_sums(self.stats_sums(t_begin, t_end))
 
+    def T_histogram(self, lo, hi, n_bins=4096, rows=None, out=None, stream=None):
+        """Fixed-bin histograms of the stored T rows on the device: int64 tensor [n_rows, n_bins]
+        (bin b counts lo + b w <= T < lo + (b+1) w; outliers land in the edge bins).  `out` lets
+        several calls / shards accumulate; percentiles: distributed.histogram_percentiles."""
+        if self.T is None:
+            raise RuntimeError("no stored T rows to histogram")
+        x = self.T if rows is None else self.T[rows].contiguous()
+        k = x.shape[0]
+        if out is None:
+            out = torch.zeros((k, int(n_bins)), dtype=torch.int64, device=self.device)
+        fn = getattr(self.lib, f"fiveeq_hist_rows_{self._sfx}")
+        with torch.cuda.device(self.device):
+            rc = fn(k, self.n_members, x.shape[1], self._ptr(x), float(lo), float(hi), int(n_bins), self._ptr(out),
+                    self._stream(stream))
+        _capi.check(self.lib, rc)
+        return out
+
     # -- accounting ----------------------------------------------------------------------
     def bytes_per_member_step(self, mode="per_step"):
         """ALGORITHMIC HBM bytes per member-timestep:

@@ -187,6 +187,16 @@ int fiveeq_run_inverse_f32(const fiveeq_model *model, int64_t n_members, int64_t
 int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time,
                         const double *e0, const double *time, double *out, void *stream);
 
+/* new — fixed-bin histograms of stored rows, for all-timestep percentiles with a tiny exchange
+ * (SURVEY.md section 8e-ii): hist[row][b] += number of members with lo + b*w <= rows[row][m] < lo + (b+1)*w,
+ * w = (hi - lo)/n_bins; values outside [lo, hi) are counted in the edge bins, NaNs are skipped.
+ *   rows dev [n_rows][ld] (e.g. T_traj), hist dev [n_rows][n_bins] uint64, ACCUMULATED INTO (zero it first;
+ *   several shards / calls may add into the same histogram), 1 <= n_bins <= 4096, n_rows <= 65535. */
+int fiveeq_hist_rows_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double *rows,
+                         double lo, double hi, int32_t n_bins, uint64_t *hist, void *stream);
+int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
+                         double lo, double hi, int32_t n_bins, uint64_t *hist, void *stream);
+
 /* new — diagnostic: STREAM-style copy dst[i] = src[i], i < n, with the SAME access shape as the
  * step kernel (one 8-byte element per lane, 512 B per wave-instruction, grid sized the same way).
  * Used to measure the achievable copy bandwidth on the box and to calibrate the rocprofv3

@@ -8,8 +8,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from fiveeqscm_amd.distributed import (gather_summary, local_moments, merge_moments, moments_from_sums,
-                                       percentiles_sorted, reduce_stats, shard_bounds)
+from fiveeqscm_amd.distributed import (gather_summary, histogram_percentiles, local_moments, merge_moments,
+                                       moments_from_sums, percentiles_sorted, reduce_stats, shard_bounds)
 
 
 def test_shard_bounds_cover_and_balance():
@@ -49,6 +49,23 @@ def test_moments_from_sums_single_process():
     assert moments_from_sums(sums)["max"].item() == 6.0
 
 
+def _np_hist(x, lo, hi, n_bins):
+    pos = np.floor((x - lo) * (n_bins / (hi - lo))).astype(np.int64).clip(0, n_bins - 1)
+    return np.stack([np.bincount(r, minlength=n_bins) for r in pos])
+
+
+def test_histogram_percentiles_within_one_bin_width():
+    rng = np.random.default_rng(3)
+    x = rng.normal(2.0, 0.8, size=(5, 200_000))
+    lo, hi, nb = -3.0, 8.0, 4096
+    h = torch.from_numpy(_np_hist(x, lo, hi, nb))
+    got, total = histogram_percentiles(h, lo, hi, (1.0, 5.0, 50.0, 95.0, 99.0))
+    want = np.percentile(x, (1.0, 5.0, 50.0, 95.0, 99.0), axis=1).T
+    assert total.tolist() == [200_000.0] * 5
+    assert np.abs(got.numpy() - want).max() < (hi - lo) / nb          # below one bin width (2.7 mK here)
+    assert np.abs(got.numpy() - want)[:, 1:4].max() < 4e-4            # in-bin interpolation: better where bins are full
+
+
 def test_single_process_summary_needs_no_process_group():
     x = torch.arange(12, dtype=torch.float64).reshape(2, 6)
     s = gather_summary(x, percentiles=(50.0,))
@@ -72,6 +89,10 @@ def _worker(rank, world, port, n_total, q):
                     and np.allclose(m["var"].numpy(), full.var(1), rtol=1e-10)
                     and np.array_equal(m["min"].numpy(), full.min(1)) and np.array_equal(m["max"].numpy(), full.max(1))
                     and m["count"].tolist() == [float(n_total)] * 3)
+        hloc = torch.from_numpy(_np_hist(full[:, lo:hi], -3.0, 6.0, 2048))
+        hp, htot = histogram_percentiles(hloc, -3.0, 6.0, (5.0, 50.0, 95.0))          # all-reduce(SUM) of the counts
+        stats_ok = bool(stats_ok and htot.tolist() == [float(n_total)] * 3
+                        and np.abs(hp.numpy() - np.percentile(full, (5.0, 50.0, 95.0), axis=1).T).max() < 9.0 / 2048)
         if rank == 0:
             want = np.percentile(full, (5.0, 50.0, 95.0), axis=1).T
             ok = (np.allclose(s["percentiles"].numpy(), want, rtol=1e-13)

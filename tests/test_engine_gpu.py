@@ -464,6 +464,44 @@ def test_on_device_stats_match_trajectory(gpu, mode, N):
     assert torch.equal(eng2.T_stats, eng.T_stats)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_histogram_kernel_and_percentiles(gpu, dtype):
+    """fiveeq_hist_rows: exact counts against NumPy (edge clamping, ragged chunk, NaN skipped, accumulation
+    into an existing histogram), and the percentiles read from it against the exact ones."""
+    from fiveeqscm_amd.distributed import histogram_percentiles
+    N, n_steps = 40_000 + 123, 60
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    eng = _engine(p, N, E, dtype=torch.float64 if dtype == "f64" else torch.float32)
+    eng.run(mode="fused")
+    torch.cuda.synchronize()
+    T = eng.T.double().cpu().numpy()
+    lo, hi, nb = -0.05, float(T.max()) * 0.9, 1024                    # hi below the maximum: exercises the edge bin
+    h = eng.T_histogram(lo, hi, nb)
+    torch.cuda.synchronize()
+    pos = np.floor((T - lo) * (nb / (hi - lo))).astype(np.int64).clip(0, nb - 1)
+    want = np.stack([np.bincount(r, minlength=nb) for r in pos])
+    got = h.cpu().numpy()
+    # a value sitting exactly on a bin edge may round differently in (v-lo)*inv_w: allow moving <= 2 counts per row
+    assert np.abs(got - want).sum(1).max() <= 4 and np.array_equal(got.sum(1), np.full(n_steps, N))
+    eng.T_histogram(lo, hi, nb, out=h)                                # accumulate: counts double
+    torch.cuda.synchronize()
+    assert np.array_equal(h.cpu().numpy(), 2 * got)
+    eng.T[5, 17] = float("nan")                                       # NaN is skipped, not binned
+    h5 = eng.T_histogram(lo, hi, nb, rows=[5])
+    assert int(h5.sum()) == N - 1
+    lo2, hi2 = float(T.min()) - 0.01, float(T.max()) + 0.01
+    hp, tot = histogram_percentiles(eng.T_histogram(lo2, hi2, 4096, rows=list(range(10, 60))), lo2, hi2, (5.0, 50.0, 95.0))
+    exact = np.percentile(T[10:60], (5.0, 50.0, 95.0), axis=1).T
+    assert np.abs(hp.cpu().numpy() - exact).max() < (hi2 - lo2) / 4096
+    # argument validation happens on the host
+    from fiveeqscm_amd import _capi
+    with pytest.raises(_capi.FiveEqError):
+        eng.T_histogram(1.0, 1.0, 16)
+    with pytest.raises(_capi.FiveEqError):
+        eng.T_histogram(0.0, 1.0, 5000)
+
+
 def test_stats_fp32_accumulate_in_fp64(gpu):
     N, n_steps = 5000, 60
     p = prm.sample_ensemble(prm.default_params("co2"), N)
