@@ -66,25 +66,26 @@ struct Layout {
 // transcendental (one per pool per member-step) and its argument is always <= 0, so a
 // range-restricted version saves the general routine's extra branches:
 //   x = k ln2 + r, |r| <= ln2/2 ;  expm1(x) = 2^k (expm1 r) + (2^k - 1)
-// with expm1(r) = r + r^2 Q(r), Q the degree-12 Taylor polynomial (truncation
-// < 1.3e-17 relative on the interval).  For k = 0 the result is expm1(r) itself, so small
+// with expm1(r) = r + r^2 Q(r), Q a degree-10 near-minimax polynomial (8.5e-19 relative).  For k = 0 the result is expm1(r) itself, so small
 // arguments (the tau ~ 1e6 yr pool: x ~ -1e-6) keep full RELATIVE accuracy.
 // ---------------------------------------------------------------------------------
-// expm1(r) on |r| <= ln2/2 as r + r^2 Q(r): shared by fe_expm1_neg and fe_exp.
+// expm1(r) on |r| <= ln2/2 as r + r^2 Q(r): shared by fe_expm1_neg and fe_exp.  Q is the degree-10
+// interpolant of (expm1(r) - r)/r^2 at the Chebyshev nodes of the interval (computed in 60-digit
+// decimal arithmetic, coefficients rounded to double): approximation error 8.5e-19 relative, where
+// the Taylor polynomial needs degree 12 for 1.2e-17.  Two fewer FMAs on each of the nine exp-type
+// calls of a three-gas member-step.
 __device__ __forceinline__ double fe_expm1_reduced(double r) {
-    double q = 1.0 / 87178291200.0;                          // 1/14!
-    q = __builtin_fma(q, r, 1.0 / 6227020800.0);             // 1/13!
-    q = __builtin_fma(q, r, 1.0 / 479001600.0);              // 1/12!
-    q = __builtin_fma(q, r, 1.0 / 39916800.0);               // 1/11!
-    q = __builtin_fma(q, r, 1.0 / 3628800.0);                // 1/10!
-    q = __builtin_fma(q, r, 1.0 / 362880.0);                 // 1/9!
-    q = __builtin_fma(q, r, 1.0 / 40320.0);                  // 1/8!
-    q = __builtin_fma(q, r, 1.0 / 5040.0);                   // 1/7!
-    q = __builtin_fma(q, r, 1.0 / 720.0);                    // 1/6!
-    q = __builtin_fma(q, r, 1.0 / 120.0);                    // 1/5!
-    q = __builtin_fma(q, r, 1.0 / 24.0);                     // 1/4!
-    q = __builtin_fma(q, r, 1.0 / 6.0);                      // 1/3!
-    q = __builtin_fma(q, r, 0.5);                            // 1/2!
+    double q = 0x1.1f72fc730b4ffp-29;
+    q = __builtin_fma(q, r, 0x1.af4ddd84882fep-26);
+    q = __builtin_fma(q, r, 0x1.27e4db67b4303p-22);
+    q = __builtin_fma(q, r, 0x1.71de02375656cp-19);
+    q = __builtin_fma(q, r, 0x1.a01a01a6d7808p-16);
+    q = __builtin_fma(q, r, 0x1.a01a01abe62ddp-13);
+    q = __builtin_fma(q, r, 0x1.6c16c16c162d6p-10);
+    q = __builtin_fma(q, r, 0x1.11111111100dfp-7);
+    q = __builtin_fma(q, r, 0x1.5555555555556p-5);
+    q = __builtin_fma(q, r, 0x1.5555555555557p-3);
+    q = __builtin_fma(q, r, 0x1.0000000000000p-1);
     return __builtin_fma(r * r, q, r);
 }
 // x = k ln2 + r with |r| <= ln2/2 (two-step Cody-Waite; ln2 hi has 32 zero low bits)
