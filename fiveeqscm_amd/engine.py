@@ -121,6 +121,25 @@ class EnsembleEngine:
         if self.cumE is not None:
             self.cumE.zero_()
 
+    def state_dict(self):
+        """Checkpoint: everything a resumed run needs besides the (immutable) parameters and drive
+        table — pools, thermal boxes and, in inverse mode, the per-member cumulative emissions —
+        as host NumPy arrays in fp64.  Resume with `load_state_dict` and `run(t, ...)`: bit-identical
+        to an uninterrupted run (checkpoint/resume)."""
+        torch.cuda.synchronize(self.device)
+        out = {"R": self.R.double().cpu().numpy(), "S": self.S.double().cpu().numpy()}
+        if self.cumE is not None:
+            out["cumE"] = self.cumE.double().cpu().numpy()
+        return out
+
+    def load_state_dict(self, state):
+        for name in ("R", "S") + (("cumE",) if self.cumE is not None else ()):
+            dst = getattr(self, name)
+            src = np.asarray(state[name], dtype=np.float64)
+            if src.shape != tuple(dst.shape):
+                raise ValueError(f"{name}: checkpoint shape {src.shape}, engine {tuple(dst.shape)}")
+            dst.copy_(torch.from_numpy(src).to(self.dtype))
+
     # -- launches ----------------------------------------------------------------------
     def _stream(self, stream=None):
         s = stream if stream is not None else torch.cuda.current_stream(self.device)

@@ -282,6 +282,25 @@ def test_step_by_step_equals_run_and_resume(gpu):
     assert torch.equal(a.C[47:], d.C[47:]) and torch.equal(a.T[47:], d.T[47:])
 
 
+def test_checkpoint_state_dict_roundtrip(gpu, tmp_path):
+    N, n_steps = 500, 90
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    whole = _engine(p, N, E)
+    whole.run()
+    first = _engine(p, N, E)
+    first.run(0, 33)
+    np.savez(tmp_path / "ck.npz", **first.state_dict())
+    second = _engine(p, N, E)
+    second.load_state_dict(dict(np.load(tmp_path / "ck.npz")))
+    second.run(33, n_steps, mode="fused")
+    torch.cuda.synchronize()
+    assert torch.equal(second.R, whole.R) and torch.equal(second.S, whole.S)
+    assert torch.equal(second.T[33:], whole.T[33:]) and torch.equal(second.C[33:], whole.C[33:])
+    with pytest.raises(ValueError):
+        second.load_state_dict({"R": np.zeros((2, 2)), "S": np.zeros((2, N))})
+
+
 def test_all_compiled_layouts_match_oracle(gpu):
     rng = np.random.default_rng(11)
     base = prm.default_params("multigas")
