@@ -210,6 +210,8 @@ def main():
     # plus the ~1-2 us dependent-launch boundary (a single bracketed launch would add the ~10 us
     # idle-stream launch latency instead and overstate the kernel).
     A = eng.bytes_per_member_step("per_step")
+    n_launch = len(eng._chunks())              # > 1 when the engine schedules chunk-major (large ensembles)
+    members_per_launch = (hi - lo) / n_launch
     per_batch = 100
     samples = []
     for i in range(max(a.kernel_batches, 1)):
@@ -220,10 +222,10 @@ def main():
         eng.run(t + 5, t + 5 + per_batch)
         e1.record()
         e1.synchronize()
-        samples.append(e0.elapsed_time(e1) * 1e-3 / per_batch)
+        samples.append(e0.elapsed_time(e1) * 1e-3 / (per_batch * n_launch))
     samples = np.array(samples)
     k_avg = float(samples.mean())
-    achieved = A * (hi - lo) / k_avg / 1e9
+    achieved = A * members_per_launch / k_avg / 1e9
     # achievable copy bandwidth on this box, same access shape (8 B/lane), buffers beyond the 256 MiB L3
     n_copy = 1 << 27                                        # 1 GiB read + 1 GiB written per launch
     src = torch.empty(n_copy, dtype=torch.float64, device=dev).normal_()
@@ -254,10 +256,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": f"fiveeq::step_kernel<{'double' if a.dtype == 'f64' else 'float'},"
                           f"{','.join(str(x) for x in (eng.pools + [0, 0])[:3])}>",
-                "algorithmic_bytes_per_member_step": A, "members_per_launch": hi - lo,
-                "algorithmic_bytes_per_launch": A * (hi - lo),
+                "algorithmic_bytes_per_member_step": A, "members_per_launch": members_per_launch,
+                "algorithmic_bytes_per_launch": A * members_per_launch,
                 "avg_launch_us": k_avg * 1e6, "min_launch_us": float(samples.min()) * 1e6,
-                "launches_timed": int(samples.size) * per_batch,
+                "launches_timed": int(samples.size) * per_batch * n_launch,
                 "stream_copy_GBs": copy_gbs, "frac_of_stream_copy": achieved / copy_gbs}
 
     # ---- end-of-run exchange (the only collective): summary statistics of T over all members ------
@@ -279,6 +281,7 @@ def main():
         "config": {"workload": f"{a.workload}: {desc}", "members_per_gpu": per_gpu, "members_total": n_total,
                    "gases": G, "pools": eng.pools, "scenario_steps": n_scen, "mode": a.mode,
                    "trajectory_stored": eng.C is not None, "parallelism": f"member-shard x{world}",
+                   "chunk_members": eng.chunk_members,
                    "collective_backend": "rccl" if backend == "nccl" else backend,
                    "emissions_sha256": emissions.emissions_sha256(E)[:16], "lhs_seed": params.LHS_SEED},
         "roofline": roofline,

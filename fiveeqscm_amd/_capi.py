@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_GAS = 3
 MAX_POOLS = 4
 N_BOX = 2

@@ -140,6 +140,7 @@ struct RunArgs {
     const T *r, *q;
     T *R, *S, *C_traj, *T_traj;
     int n_rows;
+    int n_steps;
     double* stats;
 };
 
@@ -151,7 +152,7 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
     switch (a.code) {
 #define X(p0, p1, p2)                                                                             \
     case (p0) * 100 + (p1) * 10 + (p2):                                                           \
-        hipLaunchKernelGGL((step_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, t, a.n, \
+        hipLaunchKernelGGL((step_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
                            a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);                \
         break;
         FIVEEQ_LAYOUTS(X)
@@ -171,7 +172,7 @@ int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream
     switch (a.code) {
 #define X(p0, p1, p2)                                                                                  \
     case (p0) * 100 + (p1) * 10 + (p2):                                                                \
-        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV>), grid, block, 0, st, a.km, a.drive, t_begin, \
+        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV>), grid, block, 0, st, a.km, a.drive, a.n_steps, t_begin, \
                            t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj, a.T_traj, a.n_rows,   \
                            a.stats);                                                                   \
         break;
@@ -202,6 +203,7 @@ int make_args(RunArgs<T>& a, const fiveeq_model* m, int64_t n, int64_t ld, const
     a.C_traj = C_traj;
     a.T_traj = T_traj;
     a.n_rows = n_rows;
+    a.n_steps = n_steps;
     a.stats = stats;
     return FIVEEQ_OK;
 }

@@ -380,7 +380,8 @@ __device__ __forceinline__ void store_stream(T* p, T v) {
 
 // ---------------------------------------------------------------------------------
 // Per-wave summary statistics of T for one step: (sum, sum of squares, min, max) over the wave's
-// active members, in fp64, written to stats[(t * n_waves + wave) * 4 .. +3].
+// active members, in fp64, written to stats[(wave * n_steps + t) * 4 .. +3] (wave-major, so a
+// member sub-range of a larger run addresses its records with a plain pointer offset).
 // The 64 lanes are folded in registers with DPP moves (row_shr 1/2/4/8 inside each row of 16
 // lanes, then row_bcast15 and row_bcast31 across rows: the gfx9 wave-reduce ladder); lanes with no
 // DPP source receive the operation's neutral element.  The total lands in lane 63, which writes
@@ -487,10 +488,10 @@ __device__ __forceinline__ void wave_stats_flush(const T* tile /* [STAT_STEPS][S
 // ---------------------------------------------------------------------------------
 template <typename T, int P0, int P1, int P2>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
-    const KModel<T> km, const T* __restrict__ drive, const int t, const int64_t n, const int64_t ld,
+    const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t, const int64_t n, const int64_t ld,
     const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
     T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
-    const int n_rows, double* __restrict__ stats /* [n_steps][n_waves][4] or nullptr */) {
+    const int n_rows, double* __restrict__ stats /* [n_waves][n_steps][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[DRIVE_STRIDE];
     const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
     if (stats != nullptr) {
         const int64_t n_waves = (n + 63) >> 6;
         const int64_t wave = (int64_t)blockIdx.x * (FIVEEQ_BLOCK / 64) + (threadIdx.x >> 6);
-        if (wave < n_waves) wave_stats(active, Tn, stats + ((int64_t)t * n_waves + wave) * 4);
+        if (wave < n_waves) wave_stats(active, Tn, stats + (wave * n_steps + t) * 4);
     }
 }
 
@@ -569,12 +570,12 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
 // per-member cumulative-emission state (in/out), and C_traj receives the DIAGNOSED EMISSIONS.
 template <typename T, int P0, int P1, int P2, bool INV>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
-    const KModel<T> km, const T* __restrict__ drive, const int t_begin, const int t_end,
+    const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
     const int64_t n, const int64_t ld,
     const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
     T* __restrict__ cumE /* [G][ld], INV only */,
     T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
-    const int n_rows, double* __restrict__ stats /* [n_steps][n_waves][4] or nullptr */) {
+    const int n_rows, double* __restrict__ stats /* [n_waves][n_steps][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
     __shared__ T stat_tile[FIVEEQ_BLOCK / 64][STAT_STEPS * STAT_ROW];
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
                 tile[ks * STAT_ROW + (threadIdx.x & 63)] = Tn;
                 if (++ks == STAT_STEPS || tc + k + 1 == t_end) {
                     const int64_t t_first = (int64_t)(tc + k + 1 - ks);
-                    wave_stats_flush(tile, ks, n_valid, stats + (t_first * n_waves + wave) * 4, n_waves * 4);
+                    wave_stats_flush(tile, ks, n_valid, stats + (wave * n_steps + t_first) * 4, 4);
                     ks = 0;
                 }
             }

@@ -27,7 +27,8 @@
  *   - Struct-of-arrays over ensemble members.  A "row" is one quantity for all
  *     members: row k of array X starts at X + k*ld; member m is element m of the
  *     row (0 <= m < n_members <= ld).  `ld` (leading dimension, in elements)
- *     lets a caller run a sub-range of a larger allocation.
+ *     lets a caller run a sub-range of a larger allocation — e.g. the host's chunk-major schedule
+ *     for ensembles larger than the Infinity Cache: all steps for members [0, c), then [c, 2c), ...
  *
  * MODEL STEP (identical arithmetic in every kernel; fp64 or fp32)
  *     T_old = S_0 + S_1
@@ -48,7 +49,7 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   2
+#define FIVEEQ_ABI_VERSION   3
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
@@ -97,11 +98,13 @@ typedef struct fiveeq_model {
  *   S       dev [2][ld]        thermal-box temperatures, in/out
  *   C_traj  dev [n_rows][G][ld]  concentrations of the stored steps (may be NULL)
  *   T_traj  dev [n_rows][ld]     temperature of the stored steps    (may be NULL)
- *   T_stats dev [n_steps][W][4]  fp64 (also for the f32 entry points), W = fiveeq_stats_waves(n_members):
- *                              per step and per wave of 64 members (sum T, sum T^2, min T, max T);
- *                              summing over W gives the ensemble moments of every step without a
- *                              stored trajectory (may be NULL).  Every step in the range writes all
- *                              W records of its row.
+ *   T_stats dev [W][n_steps][4]  fp64 (also for the f32 entry points), W = fiveeq_stats_waves(n_members):
+ *                              per wave of 64 members and per step (sum T, sum T^2, min T, max T);
+ *                              folding over W gives the ensemble moments of every step without a
+ *                              stored trajectory (may be NULL).  Every step in the range writes its
+ *                              record in all W wave rows.  Wave-major on purpose: a call on the member
+ *                              sub-range starting at member m0 (a multiple of 64) addresses its part of
+ *                              a larger buffer as T_stats + (m0/64)*n_steps*4.
  */
 
 /* new — library identification */

@@ -600,6 +600,34 @@ def test_sharding_invariance(gpu):
     assert torch.equal(whole.T[:, :cut], s0.T) and torch.equal(whole.T[:, cut:], s1.T)
 
 
+@pytest.mark.parametrize("mode", ["per_step", "graph"])
+def test_chunk_major_schedule_is_bit_identical(gpu, mode):
+    """Large ensembles run chunk-major (all steps for members [0,c), then [c,2c), ...) to stay inside the
+    Infinity Cache; members never interact, so every output — trajectories, state, per-wave statistics —
+    must equal the plain schedule bit for bit, ragged last chunk included."""
+    N, n_steps = 3000 + 77, 70
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    plain = _engine(p, N, E, collect_stats=True, chunk_members=None)
+    plain.run(mode=mode)
+    chunked = _engine(p, N, E, collect_stats=True, chunk_members=1024)
+    assert chunked._chunks() == [(0, 1024), (1024, 1024), (2048, 1024), (3072, 5)]
+    chunked.run(0, 31, mode=mode)
+    chunked.run(31, n_steps, mode=mode)
+    torch.cuda.synchronize()
+    for name in ("C", "T", "R", "S", "T_stats"):
+        assert torch.equal(getattr(plain, name), getattr(chunked, name)), name
+    auto = _engine(p, N, E)
+    assert auto.chunk_members == 0                      # small ensembles are not chunked
+    big = prm.default_params("multigas")
+    from fiveeqscm_amd.engine import EnsembleEngine
+    assert EnsembleEngine.auto_chunk(8_000_000, 6, 3, torch.float64) == 1_703_936
+    assert EnsembleEngine.auto_chunk(1_000_000, 6, 3, torch.float64) == 0
+    assert EnsembleEngine.auto_chunk(12_500_000, 6, 3, torch.float32) == 3_473_408
+    chunked.close()
+    plain.close()
+
+
 def test_leading_dimension_subrange(gpu):
     """ld > n_members: run the middle of a larger allocation through the raw C ABI and check the
     neighbours are untouched."""
