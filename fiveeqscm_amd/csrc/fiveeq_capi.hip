@@ -146,9 +146,9 @@ struct RunArgs {
 
 template <typename T>
 int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
-    const int64_t blocks = member_blocks(a.n);
+    const int64_t blocks = (a.n + FIVEEQ_STEP_BLOCK - 1) / FIVEEQ_STEP_BLOCK;
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
-    const dim3 grid((unsigned)blocks), block(FIVEEQ_BLOCK);
+    const dim3 grid((unsigned)blocks), block(FIVEEQ_STEP_BLOCK);
     switch (a.code) {
 #define X(p0, p1, p2)                                                                             \
     case (p0) * 100 + (p1) * 10 + (p2):                                                           \

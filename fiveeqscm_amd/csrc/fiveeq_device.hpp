@@ -15,12 +15,15 @@
 #ifndef FIVEEQ_BLOCK
 #define FIVEEQ_BLOCK 256          // threads per workgroup (4 waves: one per SIMD)
 #endif
+#ifndef FIVEEQ_STEP_BLOCK
+#define FIVEEQ_STEP_BLOCK 64      // threads per workgroup of the per-step kernel: ONE wave (measured best, below)
+#endif
 #ifndef FIVEEQ_MATH_CUSTOM
 #define FIVEEQ_MATH_CUSTOM 1      // 1: hand-written range-restricted expm1 (fp64); 0: ocml
 #endif
 #ifndef FIVEEQ_NT_STORE
 #define FIVEEQ_NT_STORE 0         // 1: non-temporal stores for the write-once trajectory rows.  Measured:
-#endif                            // no gain at 1M members, 4 % slower at 8M (profiles/r01/ab_variants.txt)
+#endif                            // within 0.5 % of plain stores at 1M and 8M members (profiles/r01/ab_variants.txt)
 #ifndef FIVEEQ_MODEL_LDS
 #define FIVEEQ_MODEL_LDS 1        // 1: shared model constants staged in LDS; 0: kernarg -> SGPRs
 #endif
@@ -482,19 +485,20 @@ __device__ __forceinline__ void wave_stats_flush(const T* tile /* [STAT_STEPS][S
 // (152 B CO2-only fp64, 248 B for pools 4+1+1 fp64).
 // The step's drive record — emissions, cumulative emissions, F_ext and the OUTPUT ROW this step
 // is stored at (drive[t][7]; negative = not stored) — is staged through LDS once per workgroup,
-// next to the shared model.  One member per lane, workgroup b owns members [256 b, 256 b + 256)
-// in every launch, so whatever state survives in its XCD's L2 / the Infinity Cache is re-hit by
-// the same XCD next step (workgroups b and b + 8 share an XCD under round-robin dispatch).
+// next to the shared model.  One member per lane; a workgroup is ONE wave of 64 members (finer
+// dispatch granularity and a trivial barrier: -2 % at 1M members, -3 % at 8M, -7 % at 100k against
+// 256-thread workgroups with identical buffers, profiles/r01/ab_variants.txt) and owns the same
+// members in every launch.
 // ---------------------------------------------------------------------------------
 template <typename T, int P0, int P1, int P2>
-__global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
+__global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
     const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t, const int64_t n, const int64_t ld,
     const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
     T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
     const int n_rows, double* __restrict__ stats /* [n_waves][n_steps][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[DRIVE_STRIDE];
-    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
+    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_STEP_BLOCK + threadIdx.x;
     const bool active = m < n;
     const int64_t mm = active ? m : n - 1;      // idle tail lanes load a valid member and store nothing
 #if FIVEEQ_MODEL_LDS
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
     // elsewhere: profiles/r01/ab_variants.txt).
     __shared__ KModel<T> km_s;
     constexpr int NW = sizeof(KModel<T>) / sizeof(T);
-    static_assert(NW <= FIVEEQ_BLOCK, "model must stage in one pass");
+    static_assert(NW <= FIVEEQ_STEP_BLOCK, "model must stage in one pass");
     const T* kargs = (const T*)__builtin_amdgcn_kernarg_segment_ptr();
     T stage_v = T(0), drv_v = T(0);
     if (threadIdx.x < NW) stage_v = kargs[threadIdx.x];
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void step_kernel(
     }
     if (stats != nullptr) {
         const int64_t n_waves = (n + 63) >> 6;
-        const int64_t wave = (int64_t)blockIdx.x * (FIVEEQ_BLOCK / 64) + (threadIdx.x >> 6);
+        const int64_t wave = (int64_t)blockIdx.x * (FIVEEQ_STEP_BLOCK / 64) + (threadIdx.x >> 6);
         if (wave < n_waves) wave_stats(active, Tn, stats + (wave * n_steps + t) * 4);
     }
 }

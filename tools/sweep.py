@@ -45,14 +45,19 @@ def main():
             p[k] = np.tile(base[k], (1, reps))[:, :N]
         for dt in a.dtypes.split(","):
             dtype = torch.float64 if dt == "f64" else torch.float32
-            engines = {lib: EnsembleEngine(p, N, E, dtype=dtype, device="cuda:0", lib_path=lib,
-                                           store_trajectory=not a.no_trajectory, collect_stats=a.stats)
-                       for lib in libs}
+            # ONE set of device buffers; the builds under test are swapped in as `eng.lib`.  (Separate
+            # engines per build showed up to 4.5 % spread between IDENTICAL libraries, purely from where
+            # their 24 GB of buffers landed.)
+            eng = EnsembleEngine(p, N, E, dtype=dtype, device="cuda:0", lib_path=libs[0],
+                                 store_trajectory=not a.no_trajectory, collect_stats=a.stats)
+            from fiveeqscm_amd import _capi
+            handles = {lib: _capi.load(lib) for lib in libs}
             for mode in a.modes.split(","):
                 times = {lib: [] for lib in libs}
                 for rnd in range(a.rounds + 1):
-                    for lib in libs:
-                        eng = engines[lib]
+                    for lib in (libs if rnd % 2 == 0 else libs[::-1]):
+                        eng.lib = handles[lib]
+                        eng.close()                               # plans belong to the previous library
                         eng.reset_state()
                         eng.run(0, 20, mode=mode)
                         torch.cuda.synchronize()
@@ -66,12 +71,11 @@ def main():
                 for lib in libs:
                     t = np.array(times[lib])
                     med = float(np.median(t))
-                    A = engines[lib].bytes_per_member_step(mode)
+                    A = eng.bytes_per_member_step(mode)
                     print(f"{os.path.basename(lib or 'default'):28s} {dt:5s} {N:9d} {mode:9s} {med:12.2f} {t.min():12.2f} "
                           f"{N / med / 1e3:15.3f} {A * N / med / 1e3:9.0f}", flush=True)
-            for eng in engines.values():
-                eng.close()
-            del engines
+            eng.close()
+            del eng
             torch.cuda.empty_cache()
 
 
