@@ -572,6 +572,7 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
 //
 // INV = true: concentration-driven form.  drive[t][0..2] are target concentrations, cumE [G][ld] is
 // per-member cumulative-emission state (in/out), and C_traj receives the DIAGNOSED EMISSIONS.
+// (112 VGPRs at fp64 4+1+1 = 4 waves/SIMD; launch-bounds hints for 5 or 6 waves spill: -3 % / -16 %.)
 template <typename T, int P0, int P1, int P2, bool INV>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
