@@ -281,14 +281,9 @@ __device__ __forceinline__ float fe_min(float a, float b) { return fminf(a, b); 
 // and returned in out[g]; the pools are then advanced with that E.
 // ---------------------------------------------------------------------------------
 template <typename T, typename L, int g, bool INV>
-__device__ __forceinline__ T gas_step(const KModel<T>& km, const T* __restrict__ drv, const T (&rr)[3 * L::G],
-                                      const T T_old, T (&R)[L::SP], T (&out)[L::G], T (&cum)[L::G]) {
-#if FIVEEQ_MODEL_LDS
-    // compiler-only barrier: keeps this gas's LDS constant reads inside this gas's code instead of
-    // all ~45 being hoisted to the kernel top (VGPR pressure) or out of the fused time loop
-    asm volatile("" ::: "memory");
-#endif
-    const KGas<T>& kg = km.gas[g];
+__device__ __forceinline__ T gas_step(const KModel<T>& km, const KGas<T>& kg, const T* __restrict__ drv,
+                                      const T (&rr)[3 * L::G], const T T_old, T (&R)[L::SP], T (&out)[L::G],
+                                      T (&cum)[L::G]) {
     constexpr int P = L::pools(g);
     constexpr int o = L::off(g);
     // --- alpha_val -----------------------------------------------------------------
@@ -344,9 +339,25 @@ __device__ __forceinline__ void member_step(const KModel<T>& km, const T* __rest
                                             T (&R)[L::SP], T (&S)[2], T (&out)[L::G], T& Tnew, T (&cum)[L::G]) {
     const T T_old = S[0] + S[1];
     T F = drv[6];
-    F += gas_step<T, L, 0, INV>(km, drv, rr, T_old, R, out, cum);
-    if constexpr (L::G > 1) F += gas_step<T, L, 1, INV>(km, drv, rr, T_old, R, out, cum);
-    if constexpr (L::G > 2) F += gas_step<T, L, 2, INV>(km, drv, rr, T_old, R, out, cum);
+    // compiler-only barriers: keep each gas's LDS constant reads inside that gas's code instead of all
+    // ~45 being hoisted to the kernel top (VGPR pressure) or out of the fused time loop.  (Issuing gas
+    // g+1's reads before gas g's arithmetic was tried: +-1 %, 133 VGPRs; not kept.)
+#if FIVEEQ_MODEL_LDS
+    asm volatile("" ::: "memory");
+#endif
+    F += gas_step<T, L, 0, INV>(km, km.gas[0], drv, rr, T_old, R, out, cum);
+    if constexpr (L::G > 1) {
+#if FIVEEQ_MODEL_LDS
+        asm volatile("" ::: "memory");
+#endif
+        F += gas_step<T, L, 1, INV>(km, km.gas[1], drv, rr, T_old, R, out, cum);
+    }
+    if constexpr (L::G > 2) {
+#if FIVEEQ_MODEL_LDS
+        asm volatile("" ::: "memory");
+#endif
+        F += gas_step<T, L, 2, INV>(km, km.gas[2], drv, rr, T_old, R, out, cum);
+    }
     // --- step_temp -------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 2; ++j) S[j] = S[j] + km.em1_d[j] * (S[j] - qq[j] * F);
