@@ -13,13 +13,13 @@
 #include <stdint.h>
 
 #ifndef FIVEEQ_BLOCK
-#define FIVEEQ_BLOCK 256          // threads per workgroup (4 waves: one per SIMD)
+#define FIVEEQ_BLOCK 256          // threads per workgroup of the fused / inverse / utility kernels (4 waves)
 #endif
 #ifndef FIVEEQ_STEP_BLOCK
 #define FIVEEQ_STEP_BLOCK 64      // threads per workgroup of the per-step kernel: ONE wave (measured best, below)
 #endif
 #ifndef FIVEEQ_MATH_CUSTOM
-#define FIVEEQ_MATH_CUSTOM 1      // 1: hand-written range-restricted expm1 (fp64); 0: ocml
+#define FIVEEQ_MATH_CUSTOM 1      // 1: hand-written expm1/exp/log/sqrt/reciprocal (fp64 and fp32); 0: device library
 #endif
 #ifndef FIVEEQ_NT_STORE
 #define FIVEEQ_NT_STORE 0         // 1: non-temporal stores for the write-once trajectory rows.  Measured:
@@ -38,9 +38,9 @@ constexpr int MAX_POOLS = 4;
 constexpr int DRIVE_STRIDE = 8;
 
 // ---------------------------------------------------------------------------------
-// Shared model in kernel precision, passed BY VALUE as a kernel argument: it lands in
-// the kernarg segment and is read with scalar loads into SGPRs — wave-uniform data
-// costs no VGPRs and no HBM traffic per member.
+// Shared model in kernel precision, passed BY VALUE as the FIRST kernel argument (496 B): it
+// lands at offset 0 of the kernarg segment, from where each workgroup stages it into LDS once
+// (stage_model below); lanes then read it with broadcast ds_reads.  No HBM traffic per member.
 // ---------------------------------------------------------------------------------
 template <typename T>
 struct KGas {
@@ -65,12 +65,13 @@ struct Layout {
 };
 
 // ---------------------------------------------------------------------------------
-// Math.  fp64: exp/log/sqrt from the device library (ocml, <= 1 ulp); expm1 is the hot
-// transcendental (one per pool per member-step) and its argument is always <= 0, so a
-// range-restricted version saves the general routine's extra branches:
+// Math.  Every transcendental of the step is written for the argument range the model can
+// produce (each pinned to <= 2 ulp against a CPU libm through fiveeq_math_probe_*).  expm1 is the
+// hot one (one per pool per member-step), always with an argument <= 0:
 //   x = k ln2 + r, |r| <= ln2/2 ;  expm1(x) = 2^k (expm1 r) + (2^k - 1)
-// with expm1(r) = r + r^2 Q(r), Q a degree-10 near-minimax polynomial (8.5e-19 relative).  For k = 0 the result is expm1(r) itself, so small
-// arguments (the tau ~ 1e6 yr pool: x ~ -1e-6) keep full RELATIVE accuracy.
+// with expm1(r) = r + r^2 Q(r), Q a degree-10 near-minimax polynomial (8.5e-19 relative).  For
+// k = 0 the result is expm1(r) itself, so small arguments (the tau ~ 1e6 yr pool: x ~ -1e-6)
+// keep full RELATIVE accuracy.
 // ---------------------------------------------------------------------------------
 // expm1(r) on |r| <= ln2/2 as r + r^2 Q(r): shared by fe_expm1_neg and fe_exp.  Q is the degree-10
 // interpolant of (expm1(r) - r)/r^2 at the Chebyshev nodes of the interval (computed in 60-digit
