@@ -263,13 +263,17 @@ def main():
                 "stream_copy_GBs": copy_gbs, "frac_of_stream_copy": achieved / copy_gbs}
 
     # ---- end-of-run exchange (the only collective): summary statistics of T over all members ------
-    summary = None
+    summary, summary_error = None, None
     if eng.T is not None:
         torch.cuda.synchronize(dev)
         ts = time.perf_counter()
         done = min(a.warmup + a.steps, n_scen)                  # scenario steps the timed run has written
         years = [t for t in (249, 499, 749) if t < done] or [done - 1]
-        summary = gather_summary(eng.T[years], percentiles=(5.0, 50.0, 95.0))
+        try:
+            summary = gather_summary(eng.T[years], percentiles=(5.0, 50.0, 95.0))
+        except Exception as exc:  # noqa: BLE001 - the exchange is outside the timed region: report, do not lose the line
+            summary = None
+            summary_error = f"{type(exc).__name__}: {exc}"
         torch.cuda.synchronize(dev)
         summary_ms = (time.perf_counter() - ts) * 1e3
 
@@ -290,6 +294,8 @@ def main():
         out["summary"] = {"years": years, "gather_ms": summary_ms,
                           "T_mean": [float(x) for x in summary["mean"]],
                           "T_p05_p50_p95": [[float(v) for v in row] for row in summary["percentiles"]]}
+    if summary_error is not None and rank == 0:
+        out["summary"] = {"error": summary_error}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kind, G, a.cpu_sample_members, n_scen)
     if rank == 0:
