@@ -253,3 +253,22 @@ def test_inverse_mode_constant_concentration_needs_decaying_emissions():
     e = inv["E"][:, 0, 0]
     assert e[0] > 100 and np.all(e[1:] > 0) and np.all(np.diff(e[1:60]) < 0)
     np.testing.assert_allclose(inv["C"][:, 0, 0], 556.0, rtol=1e-13)
+
+
+def test_one_percent_per_year_experiment_gives_tcr():
+    """The textbook TCR experiment through the concentration-driven mode: CO2 rising 1 %/yr from C0
+    doubles after 70 yr; with log forcing that is a linear ramp to F2x, and the warming at doubling
+    is TCR = F2x (q1 k1 + q2 k2) = 1.61 K for the default set (q = [0.33, 0.41], d = [239, 4.1]).
+    End-of-step forcing over a 1-yr step runs half a step ahead of the continuous ramp: +0.011 K."""
+    n = 70
+    conc = 278.0 * 1.01 ** np.arange(1, n + 1)
+    conc[-1] = 556.0
+    out = npo.run_inverse(conc[:, None], CO2, 1)
+    d, q, F2x = np.array(CO2["d"]), np.array(CO2["q"]), 3.74
+    k = 1.0 - (d / 70.0) * (1.0 - np.exp(-70.0 / d))
+    tcr = F2x * float(np.sum(q * k))
+    assert abs(tcr - 1.608) < 2e-3
+    assert 0.0 < out["T"][-1, 0] - tcr < 0.02
+    # and the emissions that sustain the ramp are positive and growing
+    e = out["E"][:, 0, 0]
+    assert np.all(e > 0) and e[-1] > e[10] > e[1]
