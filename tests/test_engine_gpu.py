@@ -374,6 +374,31 @@ def test_random_models_and_scenarios_match_oracle(gpu):
     assert worst > 0.0
 
 
+def test_minor_gas_forcing_equals_an_explicit_single_pool_gas(gpu):
+    """Host-side constant-lifetime species (minor_gases) fed in as F_ext == the same species carried on the
+    GPU as an explicit one-pool gas with alpha pinned to 1 and a linear forcing term."""
+    from fiveeqscm_amd.minor_gases import step_minor_gases
+    N, n_steps, tau, c, eff = 300, 150, 13.4, 0.5, 0.2
+    base = prm.default_params("co2")
+    p = prm.sample_ensemble(base, N)
+    E = emi.rcp_like_emissions(n_steps, 2)[:, :1]
+    Eh = 20.0 * np.abs(np.sin(np.arange(n_steps) / 17.0))
+    _, F_h = step_minor_gases(Eh, lifetime=tau, emis2conc=c, rad_eff=eff)
+    a = _engine(p, N, E, F_ext=F_h)
+    a.run()
+    r0_h = tau * (-np.expm1(-100.0 / tau))                       # iIRF_100 at alpha = 1
+    p2 = dict(p)
+    p2.update(a=[base["a"][0], [1.0, 0, 0, 0]], tau=[base["tau"][0], [tau, 1, 1, 1]], ra=[0.0, 0.0],
+              PI_conc=[278.0, 1.0], emis2conc=[base["emis2conc"][0], c], f=[base["f"][0], [0.0, eff, 0.0]],
+              r0=np.vstack([p["r0"], np.full((1, N), r0_h)]), rC=np.vstack([p["rC"], np.zeros((1, N))]),
+              rT=np.vstack([p["rT"], np.zeros((1, N))]))
+    b = _engine(p2, N, np.column_stack([E[:, 0], Eh]))
+    b.run()
+    torch.cuda.synchronize()
+    _close(b.T, a.T.cpu().numpy(), rtol=1e-11, what="T")
+    _close(b.C[:, 0], a.C[:, 0].cpu().numpy(), rtol=1e-12, what="CO2")
+
+
 def test_external_forcing_and_substeps(gpu):
     N, n_steps, dt = 500, 300, 0.25
     p = prm.sample_ensemble(prm.default_params("co2"), N)

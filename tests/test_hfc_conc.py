@@ -85,3 +85,22 @@ def test_declared_but_unwritten_reference_tests(fn):
     np.testing.assert_allclose(const, 2.0 * np.exp(-t))
     late = fn(np.array([0.0, 0.0, 10.0, 0.0, 0.0]), t, lifetime=1.0)   # pulse in year 2
     assert np.all(late == 0.0)
+
+
+def test_minor_gases_reduce_to_the_reference_function():
+    """Constant-lifetime species on the host (fiveeqscm_amd.minor_gases): an initial burden with no
+    emissions decays as the reference's calculate_hfc_conc does, for any lifetime; constant emissions
+    approach tau*c*E; the forcing is the efficiency-weighted sum."""
+    from fiveeqscm_amd.minor_gases import step_minor_gases
+    n = 30
+    conc, F = step_minor_gases(np.zeros((n, 2)), lifetime=[1.0, 13.4], emis2conc=[1.0, 0.5], rad_eff=[0.1, 0.2],
+                               R0=[10.0, 4.0])
+    t = np.arange(1, n + 1)
+    np.testing.assert_allclose(conc[:, 0], calculate_hfc_conc(np.array([10.0]), t, lifetime=1.0), rtol=1e-13)
+    np.testing.assert_allclose(conc[:, 1], 4.0 * np.exp(-t / 13.4), rtol=1e-13)
+    np.testing.assert_allclose(F, 0.1 * conc[:, 0] + 0.2 * conc[:, 1], rtol=1e-15)
+    conc, _ = step_minor_gases(np.full((400, 1), 3.0), lifetime=13.4, emis2conc=0.5, rad_eff=0.2)
+    assert abs(conc[-1, 0] - 13.4 * 0.5 * 3.0) < 1e-9
+    np.testing.assert_allclose(conc[:5, 0], 13.4 * 0.5 * 3.0 * (1 - np.exp(-np.arange(1, 6) / 13.4)), rtol=1e-13)
+    with pytest.raises(ValueError):
+        step_minor_gases(np.zeros((3, 1)), lifetime=0.0, emis2conc=1.0, rad_eff=1.0)
