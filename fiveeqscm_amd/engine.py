@@ -100,8 +100,10 @@ class EnsembleEngine:
             self.q = torch.from_numpy(np.ascontiguousarray(_rows(params["q"], 2, N, "q"))).to(dev, dt_).contiguous()
             self.R = torch.zeros((SP, N), dtype=dt_, device=dev)
             self.S = torch.zeros((2, N), dtype=dt_, device=dev)
-            self.C = torch.empty((self.n_rows, G, N), dtype=dt_, device=dev) if self.n_rows else None
-            self.T = torch.empty((self.n_rows, N), dtype=dt_, device=dev) if self.n_rows else None
+            # zero-filled, not torch.empty: rows of steps that were not run read as 0 rather than as stale
+            # device memory (and the fill touches every page once, at construction)
+            self.C = torch.zeros((self.n_rows, G, N), dtype=dt_, device=dev) if self.n_rows else None
+            self.T = torch.zeros((self.n_rows, N), dtype=dt_, device=dev) if self.n_rows else None
             self.cumE = torch.zeros((G, N), dtype=dt_, device=dev) if self.concentration_driven else None
             self.E = self.C if self.concentration_driven else None
             self.n_waves = int(self.lib.fiveeq_stats_waves(N))
