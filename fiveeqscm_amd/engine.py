@@ -96,8 +96,8 @@ class EnsembleEngine:
             self.drive = torch.from_numpy(drive).to(dev, dt_).contiguous()
             rows = np.concatenate([np.stack([_rows(params[k], G, N, k)[g] for k in ("r0", "rC", "rT")])
                                    for g in range(G)], axis=0)              # [3G, N]
-            self.r = torch.from_numpy(np.ascontiguousarray(rows)).to(dev, dt_).contiguous()
-            self.q = torch.from_numpy(np.ascontiguousarray(_rows(params["q"], 2, N, "q"))).to(dev, dt_).contiguous()
+            self.r = torch.from_numpy(np.array(rows, dtype=np.float64, order="C")).to(dev, dt_).contiguous()
+            self.q = torch.from_numpy(np.array(_rows(params["q"], 2, N, "q"), dtype=np.float64, order="C")).to(dev, dt_).contiguous()
             self.R = torch.zeros((SP, N), dtype=dt_, device=dev)
             self.S = torch.zeros((2, N), dtype=dt_, device=dev)
             # zero-filled, not torch.empty: rows of steps that were not run read as 0 rather than as stale
