@@ -743,3 +743,32 @@ def test_full_size_config5_shard_fp32_sparse_outputs(gpu):
         assert abs(st["mean"][t].item() - x.mean().item()) <= 1e-12 * abs(x.mean().item())
         assert st["min"][t].item() == x.min().item() and st["max"][t].item() == x.max().item()
     assert st["count"][0].item() == float(N)
+
+
+def test_full_size_config3_direct_parity_of_final_state(gpu):
+    """BASELINE configs[2] at full size with 1,000,000 DISTINCT Latin-hypercube members (no tiling): the
+    final pools and thermal boxes after 750 steps against the plain-C oracle run on all usable host threads
+    (~5 s on 16 threads).  The end state integrates every step's error, so this is the whole-run parity at the
+    stated tolerance over the entire hypercube, corners included."""
+    import os
+    N, n_steps = 1_000_000, 750
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    threads = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            threads = max(1, min(threads, int(int(quota) / int(period))))
+    except OSError:
+        pass
+    want = c_oracle.run(E, p, N, n_threads=min(threads, 64), keep=())
+    eng = _engine(p, N, E, output_steps=[749], collect_stats=True)
+    eng.run()
+    torch.cuda.synchronize()
+    _close(eng.R, want["R"], atol=1e-12, what="R final")
+    _close(eng.S, want["S"], what="S final")
+    T_end = want["S"][0] + want["S"][1]
+    _close(eng.T[0], T_end, what="T final")
+    st = eng.stats()
+    assert abs(st["mean"][749].item() - T_end.mean()) < 1e-12 and st["max"][749].item() == eng.T[0].max().item()
