@@ -88,6 +88,7 @@ SIGNATURES = {
     "fiveeq_hist_rows_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
     "fiveeq_hist_rows_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
     "fiveeq_stream_copy_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
+    "fiveeq_stream_copy_wide_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
     "fiveeq_math_probe_f64": (ctypes.c_int, [_i32, _i64, _p, _p, _p]),
     "fiveeq_math_probe_f32": (ctypes.c_int, [_i32, _i64, _p, _p, _p]),
 }

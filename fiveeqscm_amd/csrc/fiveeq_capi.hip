@@ -404,6 +404,19 @@ int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time, const dou
     return FIVEEQ_OK;
 }
 
+int fiveeq_stream_copy_wide_f64(int64_t n, const double* src, double* dst, void* stream) {
+    if (n < 2 || (n & 1)) return fail(FIVEEQ_E_INVALID, "n=%lld must be even and >= 2", (long long)n);
+    if (!src || !dst) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return fail(FIVEEQ_E_INVALID, "pointers must be 16-byte aligned");
+    const int64_t n2 = n / 2;
+    const int64_t tiles = (n2 + 4 * FIVEEQ_BLOCK - 1) / (4 * FIVEEQ_BLOCK);
+    const int64_t blocks = tiles < 16384 ? tiles : 16384;
+    hipLaunchKernelGGL(fiveeq::stream_copy_wide_kernel, dim3((unsigned)blocks), dim3(FIVEEQ_BLOCK), 0, (hipStream_t)stream,
+                       n2, reinterpret_cast<const double2*>(src), reinterpret_cast<double2*>(dst));
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
 int fiveeq_stream_copy_f64(int64_t n, const double* src, double* dst, void* stream) {
     if (n < 1) return fail(FIVEEQ_E_INVALID, "n=%lld must be >= 1", (long long)n);
     if (!src || !dst) return fail(FIVEEQ_E_INVALID, "NULL device pointer");

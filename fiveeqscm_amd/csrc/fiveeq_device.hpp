@@ -774,4 +774,25 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void math_probe_kernel(const int op, 
     y[i] = r;
 }
 
+// Same copy with 16 B per lane (the widest access, 1 KiB per wave-instruction) and four loads in
+// flight: the best plain copy this box does, quoted beside the 8 B/lane figure.  n must be even and
+// both pointers 16-byte aligned (checked on the host).
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void stream_copy_wide_kernel(const int64_t n2, const double2* __restrict__ src,
+                                                                        double2* __restrict__ dst) {
+    // each workgroup copies contiguous 16 KiB tiles (4 x 256 lanes x 16 B), four loads in flight per lane
+    const int64_t tile = 4 * FIVEEQ_BLOCK;
+    for (int64_t base = (int64_t)blockIdx.x * tile; base < n2; base += (int64_t)gridDim.x * tile) {
+        const int64_t i = base + threadIdx.x;
+        if (base + tile <= n2) {
+            const double2 v0 = src[i], v1 = src[i + FIVEEQ_BLOCK], v2 = src[i + 2 * FIVEEQ_BLOCK], v3 = src[i + 3 * FIVEEQ_BLOCK];
+            dst[i] = v0;
+            dst[i + FIVEEQ_BLOCK] = v1;
+            dst[i + 2 * FIVEEQ_BLOCK] = v2;
+            dst[i + 3 * FIVEEQ_BLOCK] = v3;
+        } else {
+            for (int64_t j = i; j < n2; j += FIVEEQ_BLOCK) dst[j] = src[j];
+        }
+    }
+}
+
 }  // namespace fiveeq

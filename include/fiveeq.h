@@ -205,6 +205,8 @@ int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const fl
  * Used to measure the achievable copy bandwidth on the box and to calibrate the rocprofv3
  * FETCH_SIZE / WRITE_SIZE counters on a known byte count (MI355X_MICROARCH.md, HBM section). */
 int fiveeq_stream_copy_f64(int64_t n, const double *src, double *dst, void *stream);
+/* the same copy with 16 B per lane (n even, pointers 16-byte aligned): the box's best plain copy */
+int fiveeq_stream_copy_wide_f64(int64_t n, const double *src, double *dst, void *stream);
 
 /* new — diagnostic: y[i] = f(x[i]) with one of the kernels' own fp64 math primitives, so tests can
  * pin each against a CPU libm to the ulp.  op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0, finite normal),
