@@ -44,10 +44,13 @@ class EnsembleEngine:
     """Advance N ensemble members of the five-equation model on one MI355X."""
 
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
-                 device=None, store_trajectory=True, output_steps=None, collect_stats=False,
+                 device=None, store_trajectory=True, output_steps=None, store_concentrations=True,
+                 collect_stats=False,
                  concentration_driven=False, chunk_members="auto", R0=None, S0=None, lib_path=None):
         """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
         stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
+        store_concentrations=False keeps only the T rows (a 100M-member fp32 run then stores 4 B instead
+        of 16 B per member and stored step: all 750 steps fit, and `T_histogram` gives every step's percentiles).
         collect_stats: also accumulate per-step ensemble moments of T on the device (`stats()`).
         concentration_driven: inverse mode — `emissions` holds the TARGET concentrations [n_steps, G]
         at the end of each step (shared by all members); the per-member emissions that reach them
@@ -102,7 +105,8 @@ class EnsembleEngine:
             self.S = torch.zeros((2, N), dtype=dt_, device=dev)
             # zero-filled, not torch.empty: rows of steps that were not run read as 0 rather than as stale
             # device memory (and the fill touches every page once, at construction)
-            self.C = torch.zeros((self.n_rows, G, N), dtype=dt_, device=dev) if self.n_rows else None
+            self.C = (torch.zeros((self.n_rows, G, N), dtype=dt_, device=dev)
+                      if self.n_rows and (store_concentrations or concentration_driven) else None)
             self.T = torch.zeros((self.n_rows, N), dtype=dt_, device=dev) if self.n_rows else None
             self.cumE = torch.zeros((G, N), dtype=dt_, device=dev) if self.concentration_driven else None
             self.E = self.C if self.concentration_driven else None
@@ -305,7 +309,7 @@ class EnsembleEngine:
         fused:    w (G + 1) + w (2 SP + 3 G + 6) / n_steps."""
         w = 8 if self.dtype == torch.float64 else 4
         G, SP = self.n_gas, self.sum_pools
-        out = (G + 1) * self.n_rows / self.n_steps            # stored rows only
+        out = ((G if self.C is not None else 0) + 1) * self.n_rows / self.n_steps      # stored rows only
         extra = (32.0 / 64.0) if self.T_stats is not None else 0.0   # one 32-B stats record per wave
         if mode == "fused":
             return w * (out + (2 * SP + 3 * G + 6) / self.n_steps) + extra

@@ -587,6 +587,20 @@ def test_inverse_mode_matches_oracle_and_round_trips(gpu, kind, G, N):
     assert torch.equal(two.E, inv.E) and torch.equal(two.T, inv.T) and torch.equal(two.cumE, inv.cumE)
 
 
+def test_temperature_only_storage(gpu):
+    N, n_steps = 900, 80
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    full = _engine(p, N, E)
+    full.run()
+    for mode in ("per_step", "fused"):
+        t_only = _engine(p, N, E, store_concentrations=False)
+        t_only.run(mode=mode)
+        torch.cuda.synchronize()
+        assert t_only.C is None and torch.equal(t_only.T, full.T) and torch.equal(t_only.R, full.R)
+        assert t_only.bytes_per_member_step("per_step") == 8 * (2 * 6 + 3 * 3 + 6 + 1)
+
+
 def test_fp32_kernel_tracks_fp64_oracle(gpu):
     """BASELINE configs[4] runs fp32: stay within 2e-4 relative of the fp64 oracle over 750 steps
     (increment-form updates keep the tau = 1e6 yr pool alive in fp32)."""
