@@ -28,6 +28,10 @@ _DTYPES = {torch.float64: "f64", torch.float32: "f32"}
 
 
 def _rows(x, K, N, name):
+    if isinstance(x, torch.Tensor):                    # already on a device (params.sample_ensemble_device)
+        if tuple(x.shape) != (K, N):
+            raise ValueError(f"{name}: tensor shape {tuple(x.shape)}, want [{K},{N}]")
+        return x
     x = np.asarray(x, dtype=np.float64)
     if x.ndim == 0:
         x = x.reshape(1)
@@ -97,10 +101,17 @@ class EnsembleEngine:
         dev, dt_ = self.device, dtype
         with torch.cuda.device(dev):
             self.drive = torch.from_numpy(drive).to(dev, dt_).contiguous()
-            rows = np.concatenate([np.stack([_rows(params[k], G, N, k)[g] for k in ("r0", "rC", "rT")])
-                                   for g in range(G)], axis=0)              # [3G, N]
-            self.r = torch.from_numpy(np.array(rows, dtype=np.float64, order="C")).to(dev, dt_).contiguous()
-            self.q = torch.from_numpy(np.array(_rows(params["q"], 2, N, "q"), dtype=np.float64, order="C")).to(dev, dt_).contiguous()
+            prm_rows = {k: _rows(params[k], G, N, k) for k in ("r0", "rC", "rT")}
+            q_rows = _rows(params["q"], 2, N, "q")
+            if any(isinstance(v, torch.Tensor) for v in list(prm_rows.values()) + [q_rows]):
+                as_t = lambda v: v if isinstance(v, torch.Tensor) else torch.from_numpy(np.array(v, order="C"))  # noqa: E731
+                self.r = torch.stack([as_t(prm_rows[k])[g].to(dev, dt_) for g in range(G) for k in ("r0", "rC", "rT")])
+                self.q = as_t(q_rows).to(dev, dt_).contiguous()
+            else:
+                rows = np.concatenate([np.stack([prm_rows[k][g] for k in ("r0", "rC", "rT")]) for g in range(G)],
+                                      axis=0)                                  # [3G, N]
+                self.r = torch.from_numpy(np.array(rows, dtype=np.float64, order="C")).to(dev, dt_).contiguous()
+                self.q = torch.from_numpy(np.array(q_rows, dtype=np.float64, order="C")).to(dev, dt_).contiguous()
             self.R = torch.zeros((SP, N), dtype=dt_, device=dev)
             self.S = torch.zeros((2, N), dtype=dt_, device=dev)
             # zero-filled, not torch.empty: rows of steps that were not run read as 0 rather than as stale

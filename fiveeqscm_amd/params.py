@@ -202,6 +202,45 @@ def sample_ensemble(base, n_members, seed=LHS_SEED):
     return out
 
 
+def sample_ensemble_device(base, n_members, device, seed=LHS_SEED, dtype=None):
+    """The same Latin-hypercube design as `sample_ensemble`, drawn ON THE GPU with torch's generator
+    (one `randperm` + `rand` per dimension): 12.5M members x 11 dimensions take milliseconds instead of
+    the ~4 s NumPy needs on the host, and the rows never cross PCIe.  The draws differ from the NumPy
+    ones (different generator); the design (strata, ranges, TCR/ECS rule, k_q) is identical.
+    Returns a parameter dict whose r0/rC/rT/q entries are device tensors [G,N] / [2,N]."""
+    import torch
+    G = n_gas_of(base)
+    N = int(n_members)
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    f64 = torch.float64
+
+    def lhs_row():
+        perm = torch.randperm(N, device=dev, generator=gen).to(f64)
+        return (perm + torch.rand(N, device=dev, dtype=f64, generator=gen)) / N
+
+    out = dict(base)
+    for name, lo, hi in (("r0", 0.8, 1.2), ("rC", 0.5, 1.5), ("rT", 0.5, 1.5)):
+        centre = np.asarray(base[name], dtype=np.float64).reshape(G)
+        out[name] = torch.stack([float(centre[g]) * (lo + (hi - lo) * lhs_row()) for g in range(G)])
+    tcr = 1.0 + 1.5 * lhs_row()
+    ecs = 1.5 + 3.0 * lhs_row()
+    lo_, hi_ = torch.minimum(tcr, ecs), torch.maximum(tcr, ecs)
+    swap = ecs < tcr
+    tcr = torch.where(swap, lo_, tcr)
+    ecs = torch.maximum(torch.where(swap, hi_, ecs), 1.1 * tcr)
+    d = np.asarray(base["d"], dtype=np.float64)
+    k = 1.0 - (d / 70.0) * (-np.expm1(-70.0 / d))
+    den = forcing_2x(base) * (k[0] - k[1])
+    out["q"] = torch.stack([(tcr - ecs * float(k[1])) / den, (ecs * float(k[0]) - tcr) / den])
+    out["TCR"], out["ECS"] = tcr, ecs
+    if dtype is not None:
+        for name in ("r0", "rC", "rT", "q"):
+            out[name] = out[name].to(dtype)
+    return out
+
+
 # ------------------------------------------------------------------------------------
 # pack the shared part into the C-ABI struct
 # ------------------------------------------------------------------------------------

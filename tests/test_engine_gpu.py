@@ -587,6 +587,38 @@ def test_inverse_mode_matches_oracle_and_round_trips(gpu, kind, G, N):
     assert torch.equal(two.E, inv.E) and torch.equal(two.T, inv.T) and torch.equal(two.cumE, inv.cumE)
 
 
+def test_device_side_latin_hypercube(gpu):
+    """params.sample_ensemble_device: stratified, in range, ECS >= 1.1 TCR, q = k_q(TCR, ECS); an engine built
+    from the device tensors equals one built from their host copies."""
+    N = 50_000
+    base = prm.default_params("multigas")
+    pd = prm.sample_ensemble_device(base, N, "cuda:0")
+    for name, lo, hi in (("r0", 0.8, 1.2), ("rC", 0.5, 1.5), ("rT", 0.5, 1.5)):
+        x = pd[name].cpu().numpy()
+        c = np.asarray(base[name], dtype=np.float64)[:, None]
+        assert x.shape == (3, N)
+        for g in range(3):
+            if c[g, 0] == 0:
+                assert np.all(x[g] == 0)
+                continue
+            u = (x[g] / c[g, 0] - lo) / (hi - lo)
+            assert np.array_equal(np.sort(np.floor(u * N).astype(np.int64).clip(0, N - 1)), np.arange(N))   # one per stratum
+    tcr, ecs = pd["TCR"].cpu().numpy(), pd["ECS"].cpu().numpy()
+    assert np.all(ecs >= 1.1 * tcr - 1e-12) and tcr.min() >= 1.0 and ecs.max() <= 4.5
+    np.testing.assert_allclose(pd["q"].cpu().numpy(), prm.k_q(tcr, ecs, base["d"], prm.forcing_2x(base)), rtol=1e-13)
+    assert torch.equal(pd["r0"], prm.sample_ensemble_device(base, N, "cuda:0")["r0"])          # seeded
+    E = emi.rcp_like_emissions(60, 3)
+    a = _engine(pd, N, E)
+    ph = dict(pd)
+    for k in ("r0", "rC", "rT", "q"):
+        ph[k] = pd[k].cpu().numpy()
+    b = _engine(ph, N, E)
+    a.run(mode="fused")
+    b.run(mode="fused")
+    torch.cuda.synchronize()
+    assert torch.equal(a.T, b.T) and torch.equal(a.C, b.C)
+
+
 def test_temperature_only_storage(gpu):
     N, n_steps = 900, 80
     p = prm.sample_ensemble(prm.default_params("multigas"), N)
