@@ -1,7 +1,7 @@
 import ctypes, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
-from fiveeqscm_amd import emissions, params, _capi
+from fiveeqscm_amd import emissions, params
 from fiveeqscm_amd.engine import EnsembleEngine
 N = int(sys.argv[1]); steps = 200
 base = params.sample_ensemble(params.default_params("multigas"), 65536)
