@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_GAS = 3
 MAX_POOLS = 4
 N_BOX = 2
@@ -82,6 +82,14 @@ SIGNATURES = {
     "fiveeq_plan_create_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.POINTER(_p)]),
     "fiveeq_run_inverse_f64": (ctypes.c_int, _RUN_ARGS[:11] + [_p] + _RUN_ARGS[11:]),
     "fiveeq_run_inverse_f32": (ctypes.c_int, _RUN_ARGS[:11] + [_p] + _RUN_ARGS[11:]),
+    "fiveeq_run_ksteps_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
+    "fiveeq_run_ksteps_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
+    "fiveeq_run_tiled_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
+    "fiveeq_run_tiled_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
+    "fiveeq_tile_steps_f64": (_i32, [_i32]),
+    "fiveeq_tile_steps_f32": (_i32, [_i32]),
+    "fiveeq_lhs_rows_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p, _p]),
+    "fiveeq_lhs_rows_host_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p]),
     "fiveeq_plan_launch": (ctypes.c_int, [_p, _p]),
     "fiveeq_plan_destroy": (ctypes.c_int, [_p]),
     "fiveeq_hfc_conc_f64": (ctypes.c_int, [_i64, _i64, _i32, _p, _p, _p, _p]),

@@ -10,6 +10,10 @@
 #include <cstring>
 #include <new>
 
+#ifndef FIVEEQ_FUSED_DYN_LDS
+#define FIVEEQ_FUSED_DYN_LDS 0     // experiment knob: unused dynamic LDS per fused workgroup, to cap occupancy
+#endif
+
 namespace {
 
 using namespace fiveeq;
@@ -172,7 +176,7 @@ int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream
     switch (a.code) {
 #define X(p0, p1, p2)                                                                                  \
     case (p0) * 100 + (p1) * 10 + (p2):                                                                \
-        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV>), grid, block, 0, st, a.km, a.drive, a.n_steps, t_begin, \
+        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km, a.drive, a.n_steps, t_begin, \
                            t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj, a.T_traj, a.n_rows,   \
                            a.stats);                                                                   \
         break;
@@ -236,6 +240,102 @@ int run_inverse(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, in
     if (!cumE) return fail(FIVEEQ_E_INVALID, "cumE is NULL");
     if (t_begin == t_end) return FIVEEQ_OK;
     return launch_fused<T, true>(a, t_begin, t_end, cumE, (hipStream_t)stream);
+}
+
+// ---- K steps per launch: the fused kernel over consecutive spans of k_steps ---------------------
+template <typename T>
+int run_ksteps(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
+               int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats,
+               int32_t k_steps, void* stream) {
+    RunArgs<T> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
+    if (k_steps < 1) return fail(FIVEEQ_E_INVALID, "k_steps=%d must be >= 1", k_steps);
+    for (int t = t_begin; t < t_end; t += k_steps)
+        if (int rc = launch_fused<T, false>(a, t, t + k_steps < t_end ? t + k_steps : t_end, nullptr, (hipStream_t)stream))
+            return rc;
+    return FIVEEQ_OK;
+}
+
+// ---- time-tiled persistent kernel with in-loop histograms ---------------------------------------
+constexpr int LDS_BYTES = 160 * 1024;
+template <typename T>
+constexpr int tile_static_lds() {
+    return (int)(sizeof(T) * (TILE_MAX_STEPS * DRIVE_STRIDE + (TILE_BLOCK / 64) * STAT_STEPS * STAT_ROW) + sizeof(KModel<T>));
+}
+// largest K whose histogram [K][ceil(n_bins/2)] dwords fits beside the kernel's static LDS
+template <typename T>
+int tile_steps_max(int n_bins) {
+    if (n_bins < 1) return TILE_MAX_STEPS;
+    const int hw_bytes = ((n_bins + 1) / 2) * 4;
+    const int k = (LDS_BYTES - tile_static_lds<T>() - 512) / hw_bytes;
+    return k > TILE_MAX_STEPS ? TILE_MAX_STEPS : k;
+}
+
+int device_cus() {
+    static thread_local int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached_dev = dev;
+        cached_cus = cus;
+    }
+    return cached_cus;
+}
+
+template <typename T>
+int launch_tile(const RunArgs<T>& a, int t_begin, int t_end, double lo, double inv_w, int n_bins,
+                unsigned long long* hist, hipStream_t st) {
+    const int64_t n_blocks = (a.n + TILE_BLOCK - 1) / TILE_BLOCK;
+    const int cus = device_cus();
+    const int64_t wgs = (int64_t)cus * (1024 / TILE_BLOCK);
+    const dim3 grid((unsigned)(n_blocks < wgs ? n_blocks : wgs)), block(TILE_BLOCK);
+    const size_t dyn = hist ? (size_t)(t_end - t_begin) * ((n_bins + 1) / 2) * 4 : 0;
+    switch (a.code) {
+#define X(p0, p1, p2)                                                                                        \
+    case (p0) * 100 + (p1) * 10 + (p2): {                                                                    \
+        auto kfn = tile_kernel<T, p0, p1, p2>;                                                               \
+        if (dyn > 48 * 1024)                                                                                 \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));              \
+        hipLaunchKernelGGL(kfn, grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, \
+                           a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, hist);        \
+    } break;
+        FIVEEQ_LAYOUTS(X)
+#undef X
+        default:
+            return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
+    }
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
+template <typename T>
+int run_tiled(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
+              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats,
+              int32_t k_steps, double lo, double hi, int32_t n_bins, uint64_t* hist, void* stream) {
+    RunArgs<T> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
+    double inv_w = 0.0;
+    if (hist) {
+        if (n_bins < 1 || n_bins > HIST_MAX_BINS)
+            return fail(FIVEEQ_E_INVALID, "n_bins=%d outside 1..%d", n_bins, HIST_MAX_BINS);
+        if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) return fail(FIVEEQ_E_INVALID, "need finite lo < hi");
+        inv_w = (double)n_bins / (hi - lo);
+    } else {
+        n_bins = 0;
+    }
+    const int k_max = tile_steps_max<T>(n_bins);
+    if (k_max < 1) return fail(FIVEEQ_E_INVALID, "n_bins=%d leaves no LDS for one step", n_bins);
+    if (k_steps < 0 || k_steps > k_max)
+        return fail(FIVEEQ_E_INVALID, "k_steps=%d outside 0..%d (0 = largest that fits)", k_steps, k_max);
+    if (k_steps == 0) k_steps = k_max;
+    for (int t = t_begin; t < t_end; t += k_steps)
+        if (int rc = launch_tile<T>(a, t, t + k_steps < t_end ? t + k_steps : t_end, lo, inv_w, n_bins,
+                                    reinterpret_cast<unsigned long long*>(hist), (hipStream_t)stream))
+            return rc;
+    return FIVEEQ_OK;
 }
 
 // ---- plans: the per-step launch sequence captured into a hipGraph --------------------------
@@ -371,6 +471,83 @@ int fiveeq_run_inverse_f32(const fiveeq_model* model, int64_t n_members, int64_t
                               n_rows, T_stats, stream);
 }
 
+int fiveeq_run_ksteps_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
+                          int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
+                          double* S, double* C_traj, double* T_traj, int32_t n_rows, double* T_stats, int32_t k_steps,
+                          void* stream) {
+    return run_ksteps<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                              T_stats, k_steps, stream);
+}
+int fiveeq_run_ksteps_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
+                          int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
+                          float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, int32_t k_steps,
+                          void* stream) {
+    return run_ksteps<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                             T_stats, k_steps, stream);
+}
+int fiveeq_run_tiled_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
+                         int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
+                         double* S, double* C_traj, double* T_traj, int32_t n_rows, double* T_stats, int32_t k_steps,
+                         double hist_lo, double hist_hi, int32_t n_bins, uint64_t* T_hist, void* stream) {
+    return run_tiled<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                             T_stats, k_steps, hist_lo, hist_hi, n_bins, T_hist, stream);
+}
+int fiveeq_run_tiled_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
+                         int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
+                         float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, int32_t k_steps,
+                         double hist_lo, double hist_hi, int32_t n_bins, uint64_t* T_hist, void* stream) {
+    return run_tiled<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                            T_stats, k_steps, hist_lo, hist_hi, n_bins, T_hist, stream);
+}
+int32_t fiveeq_tile_steps_f64(int32_t n_bins) { return n_bins < 0 || n_bins > fiveeq::HIST_MAX_BINS ? 0 : tile_steps_max<double>(n_bins); }
+int32_t fiveeq_tile_steps_f32(int32_t n_bins) { return n_bins < 0 || n_bins > fiveeq::HIST_MAX_BINS ? 0 : tile_steps_max<float>(n_bins); }
+
+static int lhs_check(int64_t n_total, int64_t m0, int64_t n_members, int32_t dim0, int32_t n_dim, int64_t ld) {
+    if (n_total < 1 || n_total > (1LL << 40)) return fail(FIVEEQ_E_INVALID, "n_total=%lld outside 1..2^40", (long long)n_total);
+    if (m0 < 0 || n_members < 0 || m0 + n_members > n_total)
+        return fail(FIVEEQ_E_INVALID, "members [%lld, %lld) outside [0, %lld)", (long long)m0, (long long)(m0 + n_members),
+                    (long long)n_total);
+    if (dim0 < 0 || n_dim < 0 || n_dim > 65535) return fail(FIVEEQ_E_INVALID, "dim0=%d n_dim=%d invalid", dim0, n_dim);
+    if (ld < n_members) return fail(FIVEEQ_E_INVALID, "ld < n_members");
+    return FIVEEQ_OK;
+}
+static int lhs_half_bits(int64_t n_total) {
+    int bits = 2;                                            // even number of bits with 2^bits >= n_total
+    while (bits < 62 && (1LL << bits) < n_total) bits += 2;
+    return bits / 2;
+}
+
+int fiveeq_lhs_rows_host_f64(uint64_t seed, int64_t n_total, int64_t m0, int64_t n_members, int32_t dim0, int32_t n_dim,
+                             int64_t ld, double* out) {
+    if (int rc = lhs_check(n_total, m0, n_members, dim0, n_dim, ld)) return rc;
+    if (n_members == 0 || n_dim == 0) return FIVEEQ_OK;
+    if (!out) return fail(FIVEEQ_E_INVALID, "NULL pointer");
+    const int half = lhs_half_bits(n_total);
+    for (int k = 0; k < n_dim; ++k) {
+        const uint64_t key = fiveeq::lhs_dim_key(seed, dim0 + k);
+        for (int64_t i = 0; i < n_members; ++i) {
+            const uint64_t m = (uint64_t)(m0 + i);
+            const uint64_t stratum = fiveeq::lhs_permute(m, (uint64_t)n_total, half, key);
+            const uint64_t jbits = fiveeq::lhs_mix64(m ^ (key * 0xff51afd7ed558ccdULL + 0xc4ceb9fe1a85ec53ULL)) >> 40;
+            out[(int64_t)k * ld + i] = ((double)stratum + ((double)jbits + 0.5) * 0x1.0p-24) / (double)n_total;
+        }
+    }
+    return FIVEEQ_OK;
+}
+
+int fiveeq_lhs_rows_f64(uint64_t seed, int64_t n_total, int64_t m0, int64_t n_members, int32_t dim0, int32_t n_dim,
+                        int64_t ld, double* out, void* stream) {
+    if (int rc = lhs_check(n_total, m0, n_members, dim0, n_dim, ld)) return rc;
+    if (n_members == 0 || n_dim == 0) return FIVEEQ_OK;
+    if (!out) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    const int64_t blocks = member_blocks(n_members);
+    if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
+    hipLaunchKernelGGL(fiveeq::lhs_kernel, dim3((unsigned)blocks, (unsigned)n_dim), dim3(FIVEEQ_BLOCK), 0, (hipStream_t)stream,
+                       seed, n_total, lhs_half_bits(n_total), m0, n_members, dim0, ld, out);
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
 int fiveeq_plan_launch(void* plan, void* stream) {
     Plan* p = static_cast<Plan*>(plan);
     if (!p || p->magic != PLAN_MAGIC) return fail(FIVEEQ_E_INVALID, "not a live fiveeq plan");
@@ -440,10 +617,14 @@ int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, d
     if (n_rows == 0) return FIVEEQ_OK;
     if (!rows || !hist) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
     if (n_rows > 65535) return fail(FIVEEQ_E_INVALID, "n_rows=%d exceeds the 65535 rows of one launch", n_rows);
-    const int64_t chunks = (n + fiveeq::HIST_CHUNK - 1) / fiveeq::HIST_CHUNK;
+    // members per workgroup: as coarse as still gives ~2048 workgroups over all rows (fewer, fuller flushes)
+    int64_t chunk = (n * n_rows + 2047) / 2048;
+    if (chunk < fiveeq::HIST_CHUNK_MIN) chunk = fiveeq::HIST_CHUNK_MIN;
+    chunk = (chunk + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK * FIVEEQ_BLOCK;
+    const int64_t chunks = (n + chunk - 1) / chunk;
     if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
     hipLaunchKernelGGL(fiveeq::hist_rows_kernel<T>, dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
-                       (hipStream_t)stream, n, ld, rows, lo, (double)n_bins / (hi - lo), n_bins,
+                       (hipStream_t)stream, n, ld, chunk, rows, lo, (double)n_bins / (hi - lo), n_bins,
                        reinterpret_cast<unsigned long long*>(hist));
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;

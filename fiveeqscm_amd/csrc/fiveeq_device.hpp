@@ -12,21 +12,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Floating-point contraction is OFF for this translation unit (here and in csrc/Makefile): the compiler never
+// decides which a*b+c fuse.  Every fused multiply-add of the model step is written as fe_fma() below, so
+// "per-step == fused == tiled == graph bit for bit" and the distance to the CPU oracle are properties of this
+// source, not of a hipcc release.
+#pragma clang fp contract(off)
+
 #ifndef FIVEEQ_BLOCK
 #define FIVEEQ_BLOCK 256          // threads per workgroup of the fused / inverse / utility kernels (4 waves)
 #endif
 #ifndef FIVEEQ_STEP_BLOCK
 #define FIVEEQ_STEP_BLOCK 64      // threads per workgroup of the per-step kernel: ONE wave (measured best, below)
 #endif
-#ifndef FIVEEQ_MATH_CUSTOM
-#define FIVEEQ_MATH_CUSTOM 1      // 1: hand-written expm1/exp/log/sqrt/reciprocal (fp64 and fp32); 0: device library
-#endif
-#ifndef FIVEEQ_NT_STORE
-#define FIVEEQ_NT_STORE 0         // 1: non-temporal stores for the write-once trajectory rows.  Measured:
-#endif                            // within 0.5 % of plain stores at 1M and 8M members (profiles/r01/ab_variants.txt)
-#ifndef FIVEEQ_MODEL_LDS
-#define FIVEEQ_MODEL_LDS 1        // 1: shared model constants staged in LDS; 0: kernarg -> SGPRs
-#endif
+// (Experiments that lost — device-library math, non-temporal trajectory stores, model constants in SGPRs —
+// are recorded in profiles/r01/ab_variants.txt; their code paths are gone.)
 #ifndef FIVEEQ_FUSED_CHUNK
 #define FIVEEQ_FUSED_CHUNK 125    // drive-table steps staged into LDS per refill (fused kernel)
 #endif
@@ -55,6 +54,9 @@ struct KModel {
     T iirf_max;
     T dt;
 };
+
+__device__ __forceinline__ double fe_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fe_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 template <int P0, int P1, int P2>
 struct Layout {
@@ -100,15 +102,11 @@ __device__ __forceinline__ double fe_reduce_ln2(double x, double& k) {
 }
 
 __device__ __forceinline__ double fe_expm1_neg(double x) {
-#if FIVEEQ_MATH_CUSTOM
     x = fmax(x, -800.0);                                     // exp(-800) == 0: result -1
     double k;
     const double p = fe_expm1_reduced(fe_reduce_ln2(x, k));
     const double s = __builtin_ldexp(1.0, (int)k);           // 2^k, k <= 0
     return __builtin_fma(s, p, s - 1.0);                     // k = 0: exactly p
-#else
-    return expm1(x);
-#endif
 }
 // fp32 twins of the routines above (same structure, float constants): Cody-Waite ln2 split with 12
 // zero low bits in the high part, degree-7 Taylor of expm1(r) (truncation 1.5e-8 relative).
@@ -127,60 +125,40 @@ __device__ __forceinline__ float fe_reduce_ln2(float x, float& k) {
     return __builtin_fmaf(-k, 1.42860682030941723212e-6f, r);
 }
 __device__ __forceinline__ float fe_expm1_neg(float x) {
-#if FIVEEQ_MATH_CUSTOM
     x = fmaxf(x, -100.0f);                                   // expf(-100) == 0: result -1
     float k;
     const float p = fe_expm1_reduced(fe_reduce_ln2(x, k));
     const float s = __builtin_ldexpf(1.0f, (int)k);
     return __builtin_fmaf(s, p, s - 1.0f);
-#else
-    return expm1f(x);
-#endif
 }
 
 // exp(x) for the alpha closure.  The argument is clamped to +-700 so that alpha is always a
 // finite normal number (e^+-700 ~ 1e+-304) and the Newton reciprocal below is always valid.
 __device__ __forceinline__ double fe_exp(double x) {
-#if FIVEEQ_MATH_CUSTOM
     x = fmin(fmax(x, -700.0), 700.0);
     double k;
     const double p = fe_expm1_reduced(fe_reduce_ln2(x, k));
     return __builtin_ldexp(1.0 + p, (int)k);
-#else
-    return exp(x);
-#endif
 }
 __device__ __forceinline__ float fe_exp(float x) {
     x = fminf(fmaxf(x, -80.0f), 80.0f);                      // alpha stays a finite normal float
-#if FIVEEQ_MATH_CUSTOM
     float k;
     const float p = fe_expm1_reduced(fe_reduce_ln2(x, k));
     return __builtin_ldexpf(1.0f + p, (int)k);
-#else
-    return expf(x);
-#endif
 }
 
 // 1/a for finite normal a > 0 (alpha): v_rcp_f64 seed + two Newton steps (<= 1 ulp), without the
 // scale / fixup sequence a full IEEE division needs for subnormal and infinite operands.
 __device__ __forceinline__ double fe_rcp(double a) {
-#if FIVEEQ_MATH_CUSTOM
     double y = __builtin_amdgcn_rcp(a);
     double e = __builtin_fma(-a, y, 1.0);
     y = __builtin_fma(y, e, y);
     e = __builtin_fma(-a, y, 1.0);
     return __builtin_fma(y, e, y);
-#else
-    return 1.0 / a;
-#endif
 }
 __device__ __forceinline__ float fe_rcp(float a) {
-#if FIVEEQ_MATH_CUSTOM
     const float y = __builtin_amdgcn_rcpf(a);                // v_rcp_f32 (1 ulp) + one Newton step
     return __builtin_fmaf(y, __builtin_fmaf(-a, y, 1.0f), y);
-#else
-    return 1.0f / a;
-#endif
 }
 
 // ln(x) for finite normal x > 0 (a concentration ratio).  The classic fdlibm scheme:
@@ -190,7 +168,6 @@ __device__ __forceinline__ float fe_rcp(float a) {
 // ~95 for the general device-library routine, which carries double-double arithmetic and
 // special-case selects this argument range never needs.
 __device__ __forceinline__ double fe_log(double x) {
-#if FIVEEQ_MATH_CUSTOM
     double m = __builtin_amdgcn_frexp_mant(x);                   // [0.5, 1)
     int k = __builtin_amdgcn_frexp_exp(x);
     const bool low = m < 0.70710678118654752440;
@@ -211,12 +188,8 @@ __device__ __forceinline__ double fe_log(double x) {
     const double hfsq = 0.5 * f * f;
     const double tail = __builtin_fma(dk, 1.90821492927058770002e-10, s * (hfsq + R));  // + k ln2_lo
     return __builtin_fma(dk, 6.93147180369123816490e-01, -((hfsq - tail) - f));          // k ln2_hi - ...
-#else
-    return log(x);
-#endif
 }
 __device__ __forceinline__ float fe_log(float x) {
-#if FIVEEQ_MATH_CUSTOM
     float m = __builtin_amdgcn_frexp_mantf(x);
     int k = __builtin_amdgcn_frexp_expf(x);
     const bool low = m < 0.70710678118654752440f;
@@ -233,16 +206,12 @@ __device__ __forceinline__ float fe_log(float x) {
     const float hfsq = 0.5f * f * f;
     const float tail = __builtin_fmaf(dk, 9.0580006145e-06f, s * (hfsq + R));             // + k ln2_lo
     return __builtin_fmaf(dk, 6.9313812256e-01f, -((hfsq - tail) - f));                    // k ln2_hi - ...
-#else
-    return logf(x);
-#endif
 }
 
 // sqrt(x) for finite normal x > 0 (a concentration): v_rsq_f64 seed, two Goldschmidt steps and a
 // final residual correction (<= 1 ulp), without the rescaling a full sqrt needs near the ends
 // of the exponent range.
 __device__ __forceinline__ double fe_sqrt(double x) {
-#if FIVEEQ_MATH_CUSTOM
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y;
     double h = 0.5 * y;
@@ -254,16 +223,9 @@ __device__ __forceinline__ double fe_sqrt(double x) {
     h = __builtin_fma(h, r, h);
     const double d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
-#else
-    return sqrt(x);
-#endif
 }
 __device__ __forceinline__ float fe_sqrt(float x) {
-#if FIVEEQ_MATH_CUSTOM
     return __builtin_amdgcn_sqrtf(x);                        // v_sqrt_f32: 1 ulp for normal x > 0
-#else
-    return sqrtf(x);
-#endif
 }
 __device__ __forceinline__ double fe_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ float fe_min(float a, float b) { return fminf(a, b); }
@@ -293,7 +255,7 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const KGas<T>& kg, co
     for (int i = 1; i < P; ++i) sumR += R[o + i];
     const T G_a = sumR * kg.inv_c;
     const T G_u = (INV ? cum[g] : drv[3 + g]) - G_a;
-    T iirf = rr[3 * g] + rr[3 * g + 1] * G_u + rr[3 * g + 2] * T_old + kg.ra * G_a;
+    T iirf = fe_fma(kg.ra, G_a, fe_fma(rr[3 * g + 2], T_old, fe_fma(rr[3 * g + 1], G_u, rr[3 * g])));
     iirf = fe_min(iirf, km.iirf_max);
     const T alpha = kg.g0 * fe_exp(iirf * kg.inv_g1);
     const T inv_alpha = fe_rcp(alpha);
@@ -306,11 +268,11 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const KGas<T>& kg, co
         T num = T(0), den = T(0);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            num += R[o + i] + R[o + i] * em1[i];
-            den += kg.atc[i] * em1[i];
+            num += fe_fma(R[o + i], em1[i], R[o + i]);
+            den = fe_fma(kg.atc[i], em1[i], den);
         }
         E = (num - (drv[g] - kg.C0)) / (alpha * den);
-        cum[g] += E * km.dt;
+        cum[g] = fe_fma(E, km.dt, cum[g]);
         out[g] = E;
     } else {
         E = drv[g];
@@ -320,7 +282,7 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const KGas<T>& kg, co
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const T Ri = R[o + i];
-        const T Rn = Ri + em1[i] * (Ri - kg.atc[i] * Ea);
+        const T Rn = fe_fma(em1[i], fe_fma(-kg.atc[i], Ea, Ri), Ri);     // R + em1 (R - a tau c E alpha)
         R[o + i] = Rn;
         sumN += Rn;
     }
@@ -329,8 +291,8 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const KGas<T>& kg, co
     // --- step_forc (terms whose coefficient is zero are skipped: wave-uniform branch) ---
     const bool pos = Cg > T(0);
     T Fg = kg.f2 * (Cg - kg.C0);
-    if (kg.f1 != T(0)) Fg += pos ? kg.f1 * fe_log(pos ? Cg * kg.inv_C0 : T(1)) : T(0);
-    if (kg.f3 != T(0)) Fg += kg.f3 * ((pos ? fe_sqrt(pos ? Cg : T(1)) : T(0)) - kg.sqrtC0);
+    if (kg.f1 != T(0)) Fg = pos ? fe_fma(kg.f1, fe_log(pos ? Cg * kg.inv_C0 : T(1)), Fg) : Fg;
+    if (kg.f3 != T(0)) Fg = fe_fma(kg.f3, (pos ? fe_sqrt(pos ? Cg : T(1)) : T(0)) - kg.sqrtC0, Fg);
     return Fg;
 }
 
@@ -343,25 +305,19 @@ __device__ __forceinline__ void member_step(const KModel<T>& km, const T* __rest
     // compiler-only barriers: keep each gas's LDS constant reads inside that gas's code instead of all
     // ~45 being hoisted to the kernel top (VGPR pressure) or out of the fused time loop.  (Issuing gas
     // g+1's reads before gas g's arithmetic was tried: +-1 %, 133 VGPRs; not kept.)
-#if FIVEEQ_MODEL_LDS
     asm volatile("" ::: "memory");
-#endif
     F += gas_step<T, L, 0, INV>(km, km.gas[0], drv, rr, T_old, R, out, cum);
     if constexpr (L::G > 1) {
-#if FIVEEQ_MODEL_LDS
         asm volatile("" ::: "memory");
-#endif
         F += gas_step<T, L, 1, INV>(km, km.gas[1], drv, rr, T_old, R, out, cum);
     }
     if constexpr (L::G > 2) {
-#if FIVEEQ_MODEL_LDS
         asm volatile("" ::: "memory");
-#endif
         F += gas_step<T, L, 2, INV>(km, km.gas[2], drv, rr, T_old, R, out, cum);
     }
-    // --- step_temp -------------------------------------------------------------------
+    // --- step_temp: S + em1_d (S - q F) ------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < 2; ++j) S[j] = S[j] + km.em1_d[j] * (S[j] - qq[j] * F);
+    for (int j = 0; j < 2; ++j) S[j] = fe_fma(km.em1_d[j], fe_fma(-qq[j], F, S[j]), S[j]);
     Tnew = S[0] + S[1];
 }
 template <typename T, typename L>
@@ -385,13 +341,7 @@ __device__ __forceinline__ void stage_model(KModel<T>* dst) {
 }
 
 template <typename T>
-__device__ __forceinline__ void store_stream(T* p, T v) {
-#if FIVEEQ_NT_STORE
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ void store_stream(T* p, T v) { *p = v; }   // plain stores (non-temporal: no gain, r01 A/B)
 
 // ---------------------------------------------------------------------------------
 // Per-wave summary statistics of T for one step: (sum, sum of squares, min, max) over the wave's
@@ -513,7 +463,6 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
     const int64_t m = (int64_t)blockIdx.x * FIVEEQ_STEP_BLOCK + threadIdx.x;
     const bool active = m < n;
     const int64_t mm = active ? m : n - 1;      // idle tail lanes load a valid member and store nothing
-#if FIVEEQ_MODEL_LDS
     // Issue order matters for the workgroup's critical path: first the (tiny) shared loads, then
     // all 19 row loads, and only then the LDS writes + barrier, so the staging round trip is
     // overlapped with the row round trip instead of preceding it (+1.3 % at 1M members, neutral
@@ -526,11 +475,6 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
     if (threadIdx.x < NW) stage_v = kargs[threadIdx.x];
     if (threadIdx.x < DRIVE_STRIDE) drv_v = drive[(int64_t)t * DRIVE_STRIDE + threadIdx.x];
     const KModel<T>& kmr = km_s;
-#else
-    const KModel<T>& kmr = km;
-    if (threadIdx.x < DRIVE_STRIDE) drv[threadIdx.x] = drive[(int64_t)t * DRIVE_STRIDE + threadIdx.x];
-    __syncthreads();
-#endif
 
     T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G];
 #pragma unroll
@@ -542,11 +486,9 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
 #pragma unroll
     for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
 
-#if FIVEEQ_MODEL_LDS
     if (threadIdx.x < NW) reinterpret_cast<T*>(&km_s)[threadIdx.x] = stage_v;
     if (threadIdx.x < DRIVE_STRIDE) drv[threadIdx.x] = drv_v;
     __syncthreads();
-#endif
 
     T Tn = T(0);
     {
@@ -596,13 +538,9 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
     __shared__ T stat_tile[FIVEEQ_BLOCK / 64][STAT_STEPS * STAT_ROW];
-#if FIVEEQ_MODEL_LDS
     __shared__ KModel<T> km_s;
     stage_model(&km_s);
     const KModel<T>& kmr = km_s;
-#else
-    const KModel<T>& kmr = km;
-#endif
 
     const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
     const bool active = m < n;
@@ -673,6 +611,193 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// Kernel 2b — TIME-TILED, PERSISTENT, with IN-LOOP HISTOGRAMS of T.
+//
+// Why a third shape.  All-timestep percentiles of a 100M-member run need a histogram of T for EVERY
+// step without storing T[n_steps][N].  One global atomic per member-step is out of the question
+// (scattered 64-B atomic requests: ~2e10/s chip-wide against 3e11 member-steps/s), and privatising
+// per workgroup does not help while a workgroup sees only 256 members per step — their T values land
+// in ~256 different bins.  What helps is funnelling MANY members through one LDS histogram for the
+// SAME steps.  So: one launch covers a tile of K = t_end - t_begin steps for ALL members; the grid is
+// one persistent 1024-thread workgroup per CU that walks over member blocks of 1024 — load state and
+// parameters, K steps in registers, store state — and keeps hist[K][n_bins] in LDS across all of its
+// blocks (ds_add_u32 on packed 16-bit pairs: 2 bins per dword, so K x 4096 bins = K x 8 KiB).  At the
+// end (or every 63 blocks: 63 x 1024 < 2^16, a 16-bit lane cannot overflow) the non-zero bins go to
+// the global 64-bit counters — consecutive lanes flush consecutive bins, and the occupied bins of a
+// unimodal ensemble are contiguous, so the atomics coalesce.  N/256 members per workgroup against
+// ~1000 occupied bins: 50x fewer global atomics than member-steps at 12.5M members.
+//
+// Per member-step HBM traffic: A_tile = w (2 SP + 4 + 3 G + 2) / K + stored rows + 0.5 B stats
+// (state and parameters once per K steps).  Same member_step(): bit-identical to kernels 1 and 2;
+// the bin formula is hist_rows_kernel's, so the histograms equal those of stored rows bit for bit.
+// ---------------------------------------------------------------------------------
+#ifndef FIVEEQ_TILE_BLOCK
+#define FIVEEQ_TILE_BLOCK 1024
+#endif
+constexpr int TILE_BLOCK = FIVEEQ_TILE_BLOCK;
+constexpr int TILE_MAX_STEPS = 32;
+constexpr int TILE_FLUSH_BLOCKS = 65535 / TILE_BLOCK;      // 63 * 1024 = 64512 <= 65535
+
+template <typename T, int P0, int P1, int P2>
+__global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
+    const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
+    const int64_t n, const int64_t ld,
+    const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
+    T* __restrict__ C_traj, T* __restrict__ T_traj, const int n_rows, double* __restrict__ stats,
+    const double hist_lo, const double hist_inv_w, const int n_bins,
+    unsigned long long* __restrict__ hist /* [n_steps][n_bins] or nullptr */) {
+    using L = Layout<P0, P1, P2>;
+    extern __shared__ unsigned int h_s[];                 // [nt][hw] packed 16-bit pairs (hist != nullptr)
+    __shared__ T drv[TILE_MAX_STEPS * DRIVE_STRIDE];
+    __shared__ T stat_tile[TILE_BLOCK / 64][STAT_STEPS * STAT_ROW];
+    __shared__ KModel<T> km_s;
+    {
+        constexpr int NW = sizeof(KModel<T>) / sizeof(T);
+        const T* src = (const T*)__builtin_amdgcn_kernarg_segment_ptr();
+        if (threadIdx.x < NW) reinterpret_cast<T*>(&km_s)[threadIdx.x] = src[threadIdx.x];
+    }
+    const KModel<T>& kmr = km_s;
+    const int nt = t_end - t_begin;
+    const int hw = (n_bins + 1) >> 1;
+    const bool do_hist = hist != nullptr;
+    if (do_hist)
+        for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) h_s[i] = 0u;
+    for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += TILE_BLOCK) drv[i] = drive[(int64_t)t_begin * DRIVE_STRIDE + i];
+    __syncthreads();
+
+    auto flush = [&]() {
+        for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) {
+            const unsigned int v = h_s[i];
+            if (v) {
+                const int k = i / hw, w2 = (i - k * hw) << 1;
+                unsigned long long* o = hist + (int64_t)(t_begin + k) * n_bins + w2;
+                if (v & 0xffffu) atomicAdd(o, (unsigned long long)(v & 0xffffu));
+                if (v >> 16) atomicAdd(o + 1, (unsigned long long)(v >> 16));
+                h_s[i] = 0u;
+            }
+        }
+    };
+
+    const int64_t n_blocks = (n + TILE_BLOCK - 1) / TILE_BLOCK;
+    const int64_t n_waves = (n + 63) >> 6;
+    T* const tile = stat_tile[threadIdx.x >> 6];
+    int since_flush = 0;
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int64_t m = blk * TILE_BLOCK + threadIdx.x;
+        const bool active = m < n;
+        const int64_t mm = active ? m : 0;
+        const int64_t wave = blk * (TILE_BLOCK / 64) + (threadIdx.x >> 6);
+        const bool wave_live = stats != nullptr && wave < n_waves;
+        const int n_valid = (int)min((int64_t)64, n - wave * 64);
+        int ks = 0;
+
+        T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
+#pragma unroll
+        for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + mm];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + mm];
+#pragma unroll
+        for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + mm];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
+
+        for (int k = 0; k < nt; ++k) {
+            const T* d = &drv[k * DRIVE_STRIDE];
+            member_step<T, L>(kmr, d, rr, qq, Rv, Sv, Cv, Tn);
+            const int row = __builtin_amdgcn_readfirstlane((int)d[7]);
+            if (row >= 0 && row < n_rows && active) {
+                if (C_traj != nullptr) {
+                    T* c = C_traj + (int64_t)row * L::G * ld + m;
+#pragma unroll
+                    for (int g = 0; g < L::G; ++g) store_stream(c + g * ld, Cv[g]);
+                }
+                if (T_traj != nullptr) store_stream(T_traj + (int64_t)row * ld + m, Tn);
+            }
+            if (do_hist) {
+                const double v = (double)Tn;
+                if (active && v == v) {
+                    const double pos = (v - hist_lo) * hist_inv_w;
+                    const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
+                    atomicAdd(&h_s[k * hw + (b >> 1)], (b & 1) ? 0x10000u : 1u);
+                }
+            }
+            if (wave_live) {
+                tile[ks * STAT_ROW + (threadIdx.x & 63)] = Tn;
+                if (++ks == STAT_STEPS || k + 1 == nt) {
+                    const int64_t t_first = (int64_t)(t_begin + k + 1 - ks);
+                    wave_stats_flush(tile, ks, n_valid, stats + (wave * n_steps + t_first) * 4, 4);
+                    ks = 0;
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+        }
+        if (do_hist && ++since_flush == TILE_FLUSH_BLOCKS) {     // uniform over the workgroup
+            __syncthreads();
+            flush();
+            __syncthreads();
+            since_flush = 0;
+        }
+    }
+    if (do_hist) {
+        __syncthreads();
+        flush();
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 5 — shard-computable Latin hypercube.  u[k][m - m0] for members m0 <= m < m0 + n of a
+// design over n_total members: u = (pi_k(m) + jitter_k(m)) / n_total, pi_k a KEYED BIJECTION of
+// [0, n_total) (4-round balanced Feistel network on the next even power of two, cycle-walked back
+// into range), jitter a 24-bit counter-based hash placed mid-cell, so u lies strictly inside
+// stratum pi_k(m).  Pure function of (seed, dimension, m, n_total): any rank computes exactly its
+// own members, on its own device, and the design is the same for every world size.  Integer
+// arithmetic + one exact fp64 add + one correctly rounded division: params.lhs_rows (NumPy)
+// reproduces it bit for bit.
+// ---------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t lhs_mix64(uint64_t z) {      // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t lhs_dim_key(uint64_t seed, int dim) {
+    return lhs_mix64(seed + 0x9e3779b97f4a7c15ULL * (uint64_t)(dim + 1));
+}
+__host__ __device__ __forceinline__ uint64_t lhs_permute(uint64_t m, uint64_t n_total, int half_bits, uint64_t key) {
+    const uint64_t mask = (1ULL << half_bits) - 1ULL;
+    uint64_t x = m;
+    do {
+        uint64_t left = x >> half_bits, right = x & mask;
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            const uint64_t f = lhs_mix64(right ^ (key + 0xd1342543de82ef95ULL * (uint64_t)(rnd + 1))) & mask;
+            const uint64_t nl = right;
+            right = left ^ f;
+            left = nl;
+        }
+        x = (left << half_bits) | right;
+    } while (x >= n_total);                                    // cycle-walk: the domain is < 4 n_total
+    return x;
+}
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void lhs_kernel(const uint64_t seed, const int64_t n_total, const int half_bits,
+                                                           const int64_t m0, const int64_t n, const int dim0,
+                                                           const int64_t ld, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int dim = dim0 + (int)blockIdx.y;
+    const uint64_t key = lhs_dim_key(seed, dim);
+    const uint64_t m = (uint64_t)(m0 + i);
+    const uint64_t stratum = lhs_permute(m, (uint64_t)n_total, half_bits, key);
+    const uint64_t jbits = lhs_mix64(m ^ (key * 0xff51afd7ed558ccdULL + 0xc4ceb9fe1a85ec53ULL)) >> 40;   // 24 bits
+    const double jitter = ((double)jbits + 0.5) * 0x1.0p-24;                                               // (0, 1)
+    out[(int64_t)blockIdx.y * ld + i] = ((double)stratum + jitter) / (double)n_total;
+}
+
+// ---------------------------------------------------------------------------------
 // Kernel 3 — ensemble form of the reference's calculate_hfc_conc
 // (U_FaIR/concentrations.py:5: emissions[0]*exp(-time)): out[k][m] = e0[m]*exp(-time[k]).
 // exp(-time[k]) is shared by every member: each workgroup evaluates a tile of 256 time
@@ -698,15 +823,17 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hfc_conc_kernel(
 // ---------------------------------------------------------------------------------
 // Kernel 4 — fixed-bin histograms of stored rows (all-timestep percentiles).
 // hist[row][bin] += #members with lo + bin*w <= x < lo + (bin+1)*w ; values outside [lo, hi) go to
-// the edge bins, NaNs are skipped.  One workgroup = one row x one chunk of HIST_CHUNK members:
-// privatised LDS histogram (ds_add_u32), then only the non-zero bins are added to the global
-// 64-bit counters.  Reads each stored value once: 8 (4) B per member and row.
+// the edge bins, NaNs are skipped.  One workgroup = one row x one chunk of members: privatised LDS
+// histogram (ds_add_u32), then only the non-zero bins are added to the global 64-bit counters.  The
+// host sizes the chunk so that the grid still fills the chip (>= ~2048 workgroups) but no finer: the
+// global atomics of the flush, not the read, were the cost at 16384 members per chunk (60 us per
+// 12.5M-member row in round 1).  Reads each stored value once: 8 (4) B per member and row.
 // ---------------------------------------------------------------------------------
-constexpr int HIST_CHUNK = 16384;
+constexpr int HIST_CHUNK_MIN = 16384;
 constexpr int HIST_MAX_BINS = 4096;
 
 template <typename T>
-__global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n, const int64_t ld,
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n, const int64_t ld, const int64_t chunk,
                                                                  const T* __restrict__ rows, const double lo,
                                                                  const double inv_w, const int n_bins,
                                                                  unsigned long long* __restrict__ hist) {
@@ -714,17 +841,26 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
     for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) h[b] = 0u;
     __syncthreads();
     const int64_t row = blockIdx.y;
-    const int64_t m0 = (int64_t)blockIdx.x * HIST_CHUNK;
-    const int64_t m1 = min(m0 + HIST_CHUNK, n);
+    const int64_t m0 = (int64_t)blockIdx.x * chunk;
+    const int64_t m1 = min(m0 + chunk, n);
     const T* x = rows + row * ld;
-    for (int64_t m = m0 + threadIdx.x; m < m1; m += FIVEEQ_BLOCK) {
-        const double v = (double)x[m];
+    auto count = [&](const T xv) {
+        const double v = (double)xv;
         if (v == v) {
             const double pos = (v - lo) * inv_w;
             const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
             atomicAdd(&h[b], 1u);
         }
+    };
+    int64_t m = m0 + threadIdx.x;
+    for (; m + 3 * FIVEEQ_BLOCK < m1; m += 4 * FIVEEQ_BLOCK) {      // four independent loads in flight per lane
+        const T v0 = x[m], v1 = x[m + FIVEEQ_BLOCK], v2 = x[m + 2 * FIVEEQ_BLOCK], v3 = x[m + 3 * FIVEEQ_BLOCK];
+        count(v0);
+        count(v1);
+        count(v2);
+        count(v3);
     }
+    for (; m < m1; m += FIVEEQ_BLOCK) count(x[m]);
     __syncthreads();
     unsigned long long* out = hist + row * n_bins;
     for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) {

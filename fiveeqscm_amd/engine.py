@@ -10,6 +10,8 @@ Data layout in HBM (struct-of-arrays over members; N = members of this shard):
     C      [n_rows, G, N]    concentrations of the stored steps (all steps, a selection, or none)
     T      [n_rows, N]       temperature of the stored steps
     T_stats[W, n_steps, 4]   optional per-wave (sum, sum^2, min, max) of T, W = ceil(N/64), fp64
+    T_hist [n_steps, n_bins] optional fixed-bin histogram of T for EVERY step, accumulated inside the
+                             time loop by the tiled kernel (run(mode="tiled")), int64
 
 There is no CPU path: constructing an engine without a GPU, or without the built
 HIP library, raises.  (The reference's own function, `calculate_hfc_conc`, is a
@@ -25,6 +27,9 @@ from .emissions import make_drive
 from .params import make_model, n_gas_of, pools_of
 
 _DTYPES = {torch.float64: "f64", torch.float32: "f32"}
+INFINITY_CACHE_BYTES = 256 << 20     # MI355X die-level L3 (MI355X_MICROARCH.md); sizes the chunk-major schedule
+HBM_STREAM_BYTES_PER_S = 6.7e12      # measured ceiling of the per-step kernel
+LAUNCH_BOUNDARY_S = 2.0e-6           # dependent-launch boundary on one stream (measured 1.5-2.6 us)
 
 
 def _rows(x, K, N, name):
@@ -49,13 +54,20 @@ class EnsembleEngine:
 
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
                  device=None, store_trajectory=True, output_steps=None, store_concentrations=True,
-                 collect_stats=False,
+                 collect_stats=False, hist=None, hist_ring_steps=32,
                  concentration_driven=False, chunk_members="auto", R0=None, S0=None, lib_path=None):
         """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
         stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
         store_concentrations=False keeps only the T rows (a 100M-member fp32 run then stores 4 B instead
         of 16 B per member and stored step: all 750 steps fit, and `T_histogram` gives every step's percentiles).
         collect_stats: also accumulate per-step ensemble moments of T on the device (`stats()`).
+        hist=(lo, hi, n_bins): allocate `T_hist` [n_steps, n_bins] (int64), the fixed-bin histogram of T of
+        EVERY step, for all-timestep percentiles (distributed.histogram_percentiles) without a stored
+        trajectory.  Two ways to fill it, same counts bit for bit: run(mode="tiled") accumulates it INSIDE the
+        kernel's time loop (LDS-privatised, no scratch memory); run(mode="per_step") histograms each step's T row
+        right behind the step kernel (one scratch row, still in the Infinity Cache); run(mode="fused") streams it — the fused kernel
+        parks T of `hist_ring_steps` steps at a time in a two-slot ring ([2, S, N], 0.8 GB for 12.5M fp32 members
+        at S = 16; default S = 32) and the histogram kernel drains one slot on a second HIP stream while the next is computed.
         concentration_driven: inverse mode — `emissions` holds the TARGET concentrations [n_steps, G]
         at the end of each step (shared by all members); the per-member emissions that reach them
         are diagnosed into `self.E` ([n_rows, G, N], aliasing `self.C`), and `self.cumE` [G, N] is
@@ -124,22 +136,44 @@ class EnsembleEngine:
             self.n_waves = int(self.lib.fiveeq_stats_waves(N))
             self.T_stats = (torch.zeros((self.n_waves, self.n_steps, 4), dtype=torch.float64, device=dev)
                             if collect_stats else None)
+            self.hist_spec = None
+            self.T_hist = None
+            if hist is not None:
+                lo_h, hi_h, nb = float(hist[0]), float(hist[1]), int(hist[2])
+                if not (hi_h > lo_h) or not 1 <= nb <= 4096:
+                    raise ValueError("hist=(lo, hi, n_bins): need lo < hi and 1 <= n_bins <= 4096")
+                if self.concentration_driven:
+                    raise ValueError("in-loop histograms are not available in concentration-driven mode")
+                self.hist_spec = (lo_h, hi_h, nb)
+                self.T_hist = torch.zeros((self.n_steps, nb), dtype=torch.int64, device=dev)
+            self.hist_ring_steps = max(1, min(int(hist_ring_steps), self.n_steps))
+            self._ring = None            # allocated by the first streamed-histogram run
         if chunk_members == "auto":
             chunk_members = self.auto_chunk(N, SP, G, dtype)
         self.chunk_members = int(chunk_members or 0) // 256 * 256
         self._R0 = None if R0 is None else np.asarray(R0, dtype=np.float64).reshape(SP, N)
         self._S0 = None if S0 is None else np.asarray(S0, dtype=np.float64).reshape(2, N)
+        self.t_next = 0                     # first step not yet run (bookkeeping for checkpoints)
         self.reset_state()
         self._plans = {}
 
     @staticmethod
-    def auto_chunk(n_members, sum_pools, n_gas, dtype):
-        """Members per chunk such that one chunk's state + parameter rows fill the 256 MiB Infinity
-        Cache (rounded down to 65536 members); 0 = do not chunk (the ensemble is < 1.5 chunks)."""
+    def auto_chunk(n_members, sum_pools, n_gas, dtype, cache_bytes=INFINITY_CACHE_BYTES):
+        """Members per chunk such that one chunk's state + parameter rows fill the Infinity Cache
+        (rounded down to 65536 members); 0 = do not chunk (the ensemble is < 1.5 chunks)."""
         w = 8 if dtype == torch.float64 else 4
         resident = w * (sum_pools + 2 + 3 * n_gas + 2)
-        c = ((256 << 20) // resident) // 65536 * 65536
+        c = (int(cache_bytes) // resident) // 65536 * 65536
         return c if n_members > c + c // 2 else 0
+
+    def auto_k_steps(self):
+        """Steps per launch for mode='auto': 1 (the per-step kernel) while one step's HBM traffic hides the
+        dependent-launch boundary, otherwise the K that brings a launch's traffic time to ~3 boundaries
+        (capped at 16): small ensembles are launch-bound, not bandwidth-bound."""
+        t_step = self.n_members * self.bytes_per_member_step("per_step") / HBM_STREAM_BYTES_PER_S
+        if t_step >= 3.0 * LAUNCH_BOUNDARY_S:
+            return 1
+        return int(min(16, max(2, round(3.0 * LAUNCH_BOUNDARY_S / max(t_step, 1e-9)))))
 
     # -- state -------------------------------------------------------------------------
     def reset_state(self):
@@ -154,16 +188,24 @@ class EnsembleEngine:
             self.S.copy_(torch.from_numpy(self._S0).to(self.dtype))
         if self.cumE is not None:
             self.cumE.zero_()
+        self.t_next = 0
 
-    def state_dict(self):
+    def state_dict(self, include_outputs=True):
         """Checkpoint: everything a resumed run needs besides the (immutable) parameters and drive
-        table — pools, thermal boxes and, in inverse mode, the per-member cumulative emissions —
-        as host NumPy arrays in fp64.  Resume with `load_state_dict` and `run(t, ...)`: bit-identical
-        to an uninterrupted run (checkpoint/resume)."""
+        table — pools, thermal boxes, in inverse mode the per-member cumulative emissions, the index
+        `t_next` of the first step not yet run, and (include_outputs) what the run has accumulated so
+        far: T_stats, T_hist and the stored C/T rows — as host NumPy arrays (state in fp64).  Resume with
+        `load_state_dict` and `run(state["t_next"], ...)`: bit-identical to an uninterrupted run
+        (checkpoint/resume)."""
         torch.cuda.synchronize(self.device)
-        out = {"R": self.R.double().cpu().numpy(), "S": self.S.double().cpu().numpy()}
+        out = {"R": self.R.double().cpu().numpy(), "S": self.S.double().cpu().numpy(), "t_next": int(self.t_next)}
         if self.cumE is not None:
             out["cumE"] = self.cumE.double().cpu().numpy()
+        if include_outputs:
+            for name in ("T_stats", "T_hist", "C", "T"):
+                buf = getattr(self, name)
+                if buf is not None:
+                    out[name] = buf.cpu().numpy()
         return out
 
     def load_state_dict(self, state):
@@ -173,6 +215,14 @@ class EnsembleEngine:
             if src.shape != tuple(dst.shape):
                 raise ValueError(f"{name}: checkpoint shape {src.shape}, engine {tuple(dst.shape)}")
             dst.copy_(torch.from_numpy(src).to(self.dtype))
+        self.t_next = int(state.get("t_next", 0))
+        for name in ("T_stats", "T_hist", "C", "T"):
+            dst = getattr(self, name)
+            if dst is not None and name in state:
+                src = np.asarray(state[name])
+                if src.shape != tuple(dst.shape):
+                    raise ValueError(f"{name}: checkpoint shape {src.shape}, engine {tuple(dst.shape)}")
+                dst.copy_(torch.from_numpy(src).to(dst.dtype))
 
     # -- launches ----------------------------------------------------------------------
     def _stream(self, stream=None):
@@ -223,24 +273,48 @@ class EnsembleEngine:
                     self._ptr(self.C), self._ptr(self.T), self.n_rows, self._ptr(self.T_stats),
                     self._stream(stream))
         _capi.check(self.lib, rc)
+        self.t_next = int(t) + 1
 
-    def run(self, t_begin=0, t_end=None, mode="per_step", stream=None):
+    def run(self, t_begin=0, t_end=None, mode="per_step", stream=None, k_steps=None):
         """Advance steps [t_begin, t_end).  mode:
-        'per_step' one launch per timestep, enqueued from C;
+        'per_step' one launch per timestep, enqueued from C (the north-star form);
         'graph'    the same launches replayed from a captured hipGraph;
-        'fused'    one launch, state in registers across steps (bit-identical results)."""
+        'fused'    one launch, state in registers across all steps (with `hist=`: chunks of hist_ring_steps steps, T_hist
+                   filled by the streamed pipeline, see __init__);
+        'ksteps'   the fused kernel over consecutive spans of `k_steps` steps (default `auto_k_steps()`):
+                   state crosses HBM once per k_steps — the per-step family's answer for small ensembles;
+        'tiled'    the time-tiled persistent kernel, `k_steps` steps per launch (None/0: the largest tile
+                   that fits the LDS); accumulates `T_hist` inside the time loop if the engine has `hist=`;
+        'auto'     'per_step' while a step's HBM traffic hides the launch boundary, else 'ksteps'.
+        Every mode gives bit-identical results."""
         t_end = self.n_steps if t_end is None else int(t_end)
+        if mode == "auto":
+            k_steps = self.auto_k_steps() if k_steps is None else int(k_steps)
+            mode = "per_step" if k_steps <= 1 else "ksteps"
         with torch.cuda.device(self.device):
             if self.concentration_driven:
                 rc = self._run_inverse(t_begin, t_end, stream)
+            elif mode == "per_step" and self.T_hist is not None:
+                rc = self._run_per_step_hist(t_begin, t_end, stream)
             elif mode == "per_step":
                 fn = getattr(self.lib, f"fiveeq_run_{self._sfx}")
                 rc = _capi.OK
                 for m0, n in self._chunks():                      # chunk-major: see chunk_members
                     rc = rc or fn(*self._run_args(t_begin, t_end, m0, n), self._stream(stream))
+            elif mode == "fused" and self.T_hist is not None:
+                rc = self._run_fused_streamed_hist(t_begin, t_end, stream)
             elif mode == "fused":
                 fn = getattr(self.lib, f"fiveeq_run_fused_{self._sfx}")
                 rc = fn(*self._run_args(t_begin, t_end), self._stream(stream))
+            elif mode == "ksteps":
+                k = self.auto_k_steps() if k_steps is None else int(k_steps)
+                fn = getattr(self.lib, f"fiveeq_run_ksteps_{self._sfx}")
+                rc = fn(*self._run_args(t_begin, t_end), max(k, 1), self._stream(stream))
+            elif mode == "tiled":
+                fn = getattr(self.lib, f"fiveeq_run_tiled_{self._sfx}")
+                lo_h, hi_h, nb = self.hist_spec if self.hist_spec is not None else (0.0, 1.0, 0)
+                rc = fn(*self._run_args(t_begin, t_end), int(k_steps or 0), lo_h, hi_h, nb, self._ptr(self.T_hist),
+                        self._stream(stream))
             elif mode == "graph":
                 rc = _capi.OK
                 for plan in self.prepare_graph(t_begin, t_end):
@@ -248,6 +322,99 @@ class EnsembleEngine:
             else:
                 raise ValueError(f"unknown mode {mode!r}")
         _capi.check(self.lib, rc)
+        self.t_next = t_end
+
+    def _run_per_step_hist(self, t_begin, t_end, stream):
+        """mode='per_step' with hist=: every step launch is followed by a histogram launch over the T row it has just
+        written (a one-row scratch buffer: 8 B per member, read back out of the Infinity Cache), accumulated into
+        T_hist[t].  Chunk-major like the plain per-step path: hist_rows adds each member chunk's counts."""
+        if self.C is not None:
+            raise RuntimeError("per-step histograms carry T only: build the engine with store_concentrations=False "
+                               "(or store_trajectory=False), or use mode='tiled'")
+        N = self.n_members
+        if self._ring is None or "row" not in self._ring:
+            drive = self.drive.clone()
+            drive[:, 7] = 0
+            self._ring = dict(self._ring or {}, drive0=drive, row=torch.empty((1, N), dtype=self.dtype, device=self.device))
+        drive0, row = self._ring["drive0"], self._ring["row"]
+        step = getattr(self.lib, f"fiveeq_step_{self._sfx}")
+        hist = getattr(self.lib, f"fiveeq_hist_rows_{self._sfx}")
+        lo_h, hi_h, nb = self.hist_spec
+        stored = {int(t): r for r, t in enumerate(self.out_steps)}
+        w = 8 if self.dtype == torch.float64 else 4
+        st = self._stream(stream)
+        at = lambda t, off: ctypes.c_void_p(0 if t is None else t.data_ptr() + off)   # noqa: E731
+        for m0, n in self._chunks():
+            for t in range(int(t_begin), int(t_end)):
+                rc = step(ctypes.byref(self.model), n, N, self._ptr(drive0), self.n_steps, t, at(self.r, m0 * w),
+                          at(self.q, m0 * w), at(self.R, m0 * w), at(self.S, m0 * w), ctypes.c_void_p(0), at(row, m0 * w),
+                          1, at(self.T_stats, (m0 // 64) * self.n_steps * 4 * 8), st)
+                rc = rc or hist(1, n, N, at(row, m0 * w), lo_h, hi_h, nb, self._ptr(self.T_hist[t:t + 1]), st)
+                if rc != _capi.OK:
+                    return rc
+                if t in stored:
+                    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(self.device)):
+                        self.T[stored[t], m0:m0 + n].copy_(row[0, m0:m0 + n])
+        return _capi.OK
+
+    def _run_fused_streamed_hist(self, t_begin, t_end, stream):
+        """mode='fused' with hist=: chunks of S = hist_ring_steps steps.  Stream A (the caller's) runs the fused kernel
+        for chunk i with T of every step stored into ring slot i % 2 (its own drive table: output row = t mod S);
+        stream B waits for that chunk, histograms the slot's rows into T_hist[t:t+S] (fiveeq_hist_rows_*) and copies
+        the rows of the engine's own stored years into self.T; stream A reuses a slot only after B has drained it.
+        The fused kernel is VALU-bound and the histogram pass is a read-once stream, so the two overlap."""
+        if self.C is not None:
+            raise RuntimeError("streamed histograms carry T only: build the engine with store_concentrations=False "
+                               "(or store_trajectory=False), or use mode='tiled'")
+        N, S = self.n_members, self.hist_ring_steps
+        dev = self.device
+        if self._ring is None or "buf" not in self._ring:
+            drive = self.drive.clone()
+            drive[:, 7] = torch.arange(self.n_steps, device=dev, dtype=torch.int64).remainder(S).to(self.dtype)
+            self._ring = dict(self._ring or {}, drive=drive, buf=torch.empty((2, S, N), dtype=self.dtype, device=dev),
+                              side=torch.cuda.Stream(device=dev), drained=[torch.cuda.Event(), torch.cuda.Event()])
+        ring = self._ring
+        main = stream if stream is not None else torch.cuda.current_stream(dev)
+        side = ring["side"]
+        side.wait_stream(main)                   # T_hist / self.T may have been touched on the caller's stream
+        fused = getattr(self.lib, f"fiveeq_run_fused_{self._sfx}")
+        hist = getattr(self.lib, f"fiveeq_hist_rows_{self._sfx}")
+        lo_h, hi_h, nb = self.hist_spec
+        stored = {int(t): row for row, t in enumerate(self.out_steps)}
+        used = [False, False]
+        rc = _capi.OK
+        t = int(t_begin)
+        i = 0
+        while t < t_end and rc == _capi.OK:
+            t1 = min(t_end, (t // S + 1) * S)              # chunks end on multiples of S: row = t mod S never wraps
+            slot = i % 2
+            buf = ring["buf"][slot]
+            if used[slot]:
+                main.wait_event(ring["drained"][slot])
+            rc = fused(ctypes.byref(self.model), N, N, self._ptr(ring["drive"]), self.n_steps, t, t1, self._ptr(self.r),
+                       self._ptr(self.q), self._ptr(self.R), self._ptr(self.S), ctypes.c_void_p(0), self._ptr(buf), S,
+                       self._ptr(self.T_stats), ctypes.c_void_p(main.cuda_stream))
+            side.wait_stream(main)
+            if rc == _capi.OK:
+                r0 = t % S
+                rows = buf[r0:r0 + (t1 - t)]
+                rc = hist(t1 - t, N, N, self._ptr(rows), lo_h, hi_h, nb, self._ptr(self.T_hist[t:t1]),
+                          ctypes.c_void_p(side.cuda_stream))
+                with torch.cuda.stream(side):
+                    for tt in range(t, t1):
+                        if tt in stored:
+                            self.T[stored[tt]].copy_(buf[tt % S])
+                ring["drained"][slot].record(side)
+                used[slot] = True
+            t = t1
+            i += 1
+        main.wait_stream(side)
+        return rc
+
+    def tile_steps(self):
+        """Steps per launch of mode='tiled' when k_steps is left to the library (LDS budget)."""
+        nb = self.hist_spec[2] if self.hist_spec is not None else 0
+        return int(getattr(self.lib, f"fiveeq_tile_steps_{self._sfx}")(nb))
 
     def prepare_graph(self, t_begin=0, t_end=None):
         """Capture (once) the per-step launches of [t_begin, t_end) into hipGraph plans, one per
@@ -314,16 +481,20 @@ class EnsembleEngine:
         return out
 
     # -- accounting ----------------------------------------------------------------------
-    def bytes_per_member_step(self, mode="per_step"):
+    def bytes_per_member_step(self, mode="per_step", k_steps=None):
         """ALGORITHMIC HBM bytes per member-timestep:
-        per_step: w (2 SP + 4 G + 7)   [R,S read+write; r,q read; C,T write];
-        fused:    w (G + 1) + w (2 SP + 3 G + 6) / n_steps."""
+        per_step:        w (2 SP + 4 G + 7)   [R,S read+write; r,q read; C,T write];
+        fused:           w (G + 1) + w (2 SP + 3 G + 6) / n_steps;
+        ksteps / tiled:  w (G + 1) + w (2 SP + 3 G + 6) / k_steps  (state + parameters once per k_steps)."""
         w = 8 if self.dtype == torch.float64 else 4
         G, SP = self.n_gas, self.sum_pools
         out = ((G if self.C is not None else 0) + 1) * self.n_rows / self.n_steps      # stored rows only
         extra = (32.0 / 64.0) if self.T_stats is not None else 0.0   # one 32-B stats record per wave
         if mode == "fused":
             return w * (out + (2 * SP + 3 * G + 6) / self.n_steps) + extra
+        if mode in ("ksteps", "tiled"):
+            k = k_steps or (self.auto_k_steps() if mode == "ksteps" else self.tile_steps())
+            return w * (out + (2 * SP + 3 * G + 6) / max(int(k), 1)) + extra
         return w * (2 * SP + 3 * G + 6 + out) + extra
 
 

@@ -202,40 +202,128 @@ def sample_ensemble(base, n_members, seed=LHS_SEED):
     return out
 
 
-def sample_ensemble_device(base, n_members, device, seed=LHS_SEED, dtype=None):
-    """The same Latin-hypercube design as `sample_ensemble`, drawn ON THE GPU with torch's generator
-    (one `randperm` + `rand` per dimension): 12.5M members x 11 dimensions take milliseconds instead of
-    the ~4 s NumPy needs on the host, and the rows never cross PCIe.  The draws differ from the NumPy
-    ones (different generator); the design (strata, ranges, TCR/ECS rule, k_q) is identical.
-    Returns a parameter dict whose r0/rC/rT/q entries are device tensors [G,N] / [2,N]."""
+# ------------------------------------------------------------------------------------
+# Shard-computable Latin hypercube: the design of the multi-GPU runs.
+# `latin_hypercube` above permutes [0, N) with a generator, so every rank would have to draw all N
+# members to find its own; here the permutation is a KEYED BIJECTION evaluated member by member
+# (cycle-walked 4-round Feistel network, splitmix64 round function), so a rank computes exactly
+# its shard — on its GPU through fiveeq_lhs_rows_f64, or on the host with the NumPy twin below,
+# bit for bit the same numbers — and the design does not depend on the world size.
+# ------------------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(z):
+    """splitmix64 finaliser on uint64 arrays (wrapping arithmetic)."""
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _lhs_half_bits(n_total):
+    bits = 2
+    while bits < 62 and (1 << bits) < n_total:
+        bits += 2
+    return bits // 2
+
+
+def _lhs_dim_key(seed, dim):
+    with np.errstate(over="ignore"):
+        return _mix64(np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.uint64(dim + 1))
+
+
+def lhs_permute(m, n_total, key):
+    """pi(m): keyed bijection of [0, n_total) — include/fiveeq.h, fiveeq_lhs_rows_f64."""
+    half = np.uint64(_lhs_half_bits(n_total))
+    mask = np.uint64((1 << int(half)) - 1)
+    x = np.array(m, dtype=np.uint64, copy=True)
+    todo = np.ones(x.shape, dtype=bool)
+    with np.errstate(over="ignore"):
+        while todo.any():
+            v = x[todo]
+            left, right = v >> half, v & mask
+            for rnd in range(4):
+                f = _mix64(right ^ (key + np.uint64(0xD1342543DE82EF95) * np.uint64(rnd + 1))) & mask
+                left, right = right, left ^ f
+            v = (left << half) | right
+            x[todo] = v
+            todo[todo] = v >= np.uint64(n_total)
+    return x
+
+
+def lhs_rows(n_total, dims, lo=0, hi=None, seed=LHS_SEED):
+    """[len(dims), hi-lo] fp64: u_d(m) = (pi_d(m) + jitter_d(m)) / n_total for members lo <= m < hi of a
+    Latin hypercube over n_total members; one member per stratum in every dimension."""
+    hi = n_total if hi is None else hi
+    if not 0 <= lo <= hi <= n_total:
+        raise ValueError(f"members [{lo}, {hi}) outside [0, {n_total})")
+    m = np.arange(lo, hi, dtype=np.uint64)
+    out = np.empty((len(dims), hi - lo), dtype=np.float64)
+    with np.errstate(over="ignore"):
+        for k, d in enumerate(dims):
+            key = _lhs_dim_key(seed, int(d))
+            stratum = lhs_permute(m, n_total, key)
+            jbits = _mix64(m ^ (key * np.uint64(0xFF51AFD7ED558CCD) + np.uint64(0xC4CEB9FE1A85EC53))) >> np.uint64(40)
+            jitter = (jbits.astype(np.float64) + 0.5) * 2.0 ** -24
+            out[k] = (stratum.astype(np.float64) + jitter) / float(n_total)
+    return out
+
+
+def lhs_rows_device(n_total, dims, lo, hi, device, seed=LHS_SEED):
+    """The same rows computed on `device` by the HIP kernel (dims must be consecutive)."""
+    import ctypes
+
     import torch
-    G = n_gas_of(base)
-    N = int(n_members)
+    dims = list(dims)
+    if dims != list(range(dims[0], dims[0] + len(dims))):
+        raise ValueError("dims must be consecutive")
+    lib = _capi.load()
     dev = torch.device(device)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(int(seed))
-    f64 = torch.float64
+    out = torch.empty((len(dims), hi - lo), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.fiveeq_lhs_rows_f64(int(seed), int(n_total), int(lo), int(hi - lo), dims[0], len(dims), hi - lo,
+                                     ctypes.c_void_p(out.data_ptr()),
+                                     ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _capi.check(lib, rc)
+    return out
 
-    def lhs_row():
-        perm = torch.randperm(N, device=dev, generator=gen).to(f64)
-        return (perm + torch.rand(N, device=dev, dtype=f64, generator=gen)) / N
 
+def sample_ensemble_shard(base, n_total, lo=0, hi=None, seed=LHS_SEED, device=None, dtype=None):
+    """Members [lo, hi) of the n_total-member design: the perturbation rule of `sample_ensemble` (r0 x0.8..1.2,
+    rC, rT x0.5..1.5 per gas; TCR in [1,2.5] K, ECS in [1.5,4.5] K, swapped where ECS < TCR, then
+    ECS >= 1.1 TCR; q from k_q) on the shard-computable hypercube above.  O(hi - lo) work and memory.
+    device=None: NumPy rows on the host; a torch device: rows are produced on that GPU (no PCIe, no
+    host copy) and every per-member entry is a device tensor.  Both give bit-identical numbers, and
+    concatenating the shards of any partition of [0, n_total) gives the single-shard result."""
+    G = n_gas_of(base)
+    hi = n_total if hi is None else hi
+    dims = list(range(3 * G + 2))
+    if device is None:
+        u = lhs_rows(n_total, dims, lo, hi, seed)
+        xp_min, xp_max, xp_where, xp_stack = np.minimum, np.maximum, np.where, np.stack
+    else:
+        import torch
+        u = lhs_rows_device(n_total, dims, lo, hi, device, seed)
+        xp_min, xp_max, xp_where, xp_stack = torch.minimum, torch.maximum, torch.where, torch.stack
     out = dict(base)
-    for name, lo, hi in (("r0", 0.8, 1.2), ("rC", 0.5, 1.5), ("rT", 0.5, 1.5)):
+    for j, (name, a, b) in enumerate((("r0", 0.8, 1.2), ("rC", 0.5, 1.5), ("rT", 0.5, 1.5))):
         centre = np.asarray(base[name], dtype=np.float64).reshape(G)
-        out[name] = torch.stack([float(centre[g]) * (lo + (hi - lo) * lhs_row()) for g in range(G)])
-    tcr = 1.0 + 1.5 * lhs_row()
-    ecs = 1.5 + 3.0 * lhs_row()
-    lo_, hi_ = torch.minimum(tcr, ecs), torch.maximum(tcr, ecs)
+        # one rounding per operation on both back ends: (b - a) * u, + a, * centre
+        out[name] = xp_stack([((b - a) * u[j * G + g] + a) * float(centre[g]) for g in range(G)])
+    tcr = 1.5 * u[3 * G] + 1.0
+    ecs = 3.0 * u[3 * G + 1] + 1.5
+    lo_, hi_ = xp_min(tcr, ecs), xp_max(tcr, ecs)
     swap = ecs < tcr
-    tcr = torch.where(swap, lo_, tcr)
-    ecs = torch.maximum(torch.where(swap, hi_, ecs), 1.1 * tcr)
+    tcr = xp_where(swap, lo_, tcr)
+    ecs = xp_max(xp_where(swap, hi_, ecs), 1.1 * tcr)
     d = np.asarray(base["d"], dtype=np.float64)
     k = 1.0 - (d / 70.0) * (-np.expm1(-70.0 / d))
-    den = forcing_2x(base) * (k[0] - k[1])
-    out["q"] = torch.stack([(tcr - ecs * float(k[1])) / den, (ecs * float(k[0]) - tcr) / den])
+    # multiply by the reciprocal on both back ends (torch turns a division by a scalar into that on the GPU
+    # anyway): one rounding per operation, identical on host and device
+    inv_den = 1.0 / float(forcing_2x(base) * (k[0] - k[1]))
+    out["q"] = xp_stack([(tcr - ecs * float(k[1])) * inv_den, (ecs * float(k[0]) - tcr) * inv_den])
     out["TCR"], out["ECS"] = tcr, ecs
-    if dtype is not None:
+    if dtype is not None and device is not None:
         for name in ("r0", "rC", "rT", "q"):
             out[name] = out[name].to(dtype)
     return out

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   3
+#define FIVEEQ_ABI_VERSION   4
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
@@ -167,6 +167,47 @@ int fiveeq_run_fused_f32(const fiveeq_model *model, int64_t n_members, int64_t l
                          const float *r, const float *q, float *R, float *S,
                          float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, void *stream);
 
+/* K STEPS PER LAUNCH: the time-fused kernel over consecutive spans of k_steps
+ * — state and parameters cross HBM once per k_steps instead of every step, A_K = w(G+1)[stored rows]
+ * + w(2SP+3G+6)/k_steps.  The form for ensembles too small to hide the ~2 us dependent-launch boundary
+ * behind one step of HBM traffic (10k members: 2.6 us per launch against 0.2 us of traffic).
+ * Bit-identical results to the per-step path. */
+int fiveeq_run_ksteps_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                          const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                          const double *r, const double *q, double *R, double *S,
+                          double *C_traj, double *T_traj, int32_t n_rows, double *T_stats,
+                          int32_t k_steps, void *stream);
+int fiveeq_run_ksteps_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                          const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                          const float *r, const float *q, float *R, float *S,
+                          float *C_traj, float *T_traj, int32_t n_rows, double *T_stats,
+                          int32_t k_steps, void *stream);
+
+/* TIME-TILED persistent kernel with IN-LOOP HISTOGRAMS of T: all-timestep
+ * percentiles of an ensemble that stores no trajectory.  One launch per tile of k_steps steps
+ * (0 = the largest tile whose LDS histogram fits, fiveeq_tile_steps_*(n_bins)); one persistent
+ * 1024-thread workgroup per CU walks over member blocks and accumulates
+ *     T_hist[t][b] += #members with hist_lo + b*w <= T(t) < hist_lo + (b+1)*w,  w = (hist_hi - hist_lo)/n_bins
+ * (outliers in the edge bins, NaNs skipped: the rule of fiveeq_hist_rows_*, bit for bit) in LDS,
+ * flushing only non-zero bins to T_hist dev [n_steps][n_bins] uint64 (ACCUMULATED INTO: zero it
+ * first; shards may share it).  T_hist may be NULL (no histogram; n_bins ignored).  C_traj, T_traj,
+ * T_stats behave as in the other entry points; results are bit-identical to them. */
+int fiveeq_run_tiled_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                         const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                         const double *r, const double *q, double *R, double *S,
+                         double *C_traj, double *T_traj, int32_t n_rows, double *T_stats,
+                         int32_t k_steps, double hist_lo, double hist_hi, int32_t n_bins,
+                         uint64_t *T_hist, void *stream);
+int fiveeq_run_tiled_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                         const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                         const float *r, const float *q, float *R, float *S,
+                         float *C_traj, float *T_traj, int32_t n_rows, double *T_stats,
+                         int32_t k_steps, double hist_lo, double hist_hi, int32_t n_bins,
+                         uint64_t *T_hist, void *stream);
+/* largest k_steps the tiled kernel accepts for n_bins (0 = no histogram); 0 for an invalid n_bins */
+int32_t fiveeq_tile_steps_f64(int32_t n_bins);
+int32_t fiveeq_tile_steps_f32(int32_t n_bins);
+
 /* CONCENTRATION-DRIVEN (inverse) mode (the reference's module name
  * `concentrations` hints at it, no reference code exists).  drive[t][0..2] hold the TARGET
  * concentration of each gas at the end of step t (shared by all members; columns 3..5 unused);
@@ -199,6 +240,20 @@ int fiveeq_hist_rows_f64(int32_t n_rows, int64_t n_members, int64_t ld, const do
                          double lo, double hi, int32_t n_bins, uint64_t *hist, void *stream);
 int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
                          double lo, double hi, int32_t n_bins, uint64_t *hist, void *stream);
+
+/* new — shard-computable Latin hypercube: out[k][i] = u_{dim0+k}(m0 + i),
+ * 0 <= i < n_members, 0 <= k < n_dim, for a design over n_total members:
+ *     u_d(m) = (pi_d(m) + jitter_d(m)) / n_total
+ * with pi_d a keyed bijection of [0, n_total) (cycle-walked 4-round Feistel network) and jitter a
+ * 24-bit counter-based hash in (0,1): exactly one member per stratum and dimension, and a pure
+ * function of (seed, d, m, n_total) — every rank computes only its own members, on its own device,
+ * and gets the same design whatever the world size.  out dev [n_dim][ld] fp64.
+ * Host twin (bit-identical): fiveeqscm_amd.params.lhs_rows. */
+int fiveeq_lhs_rows_f64(uint64_t seed, int64_t n_total, int64_t m0, int64_t n_members,
+                        int32_t dim0, int32_t n_dim, int64_t ld, double *out, void *stream);
+/* the same rows into HOST memory, computed on the calling thread by the same functions (no GPU needed) */
+int fiveeq_lhs_rows_host_f64(uint64_t seed, int64_t n_total, int64_t m0, int64_t n_members,
+                             int32_t dim0, int32_t n_dim, int64_t ld, double *out);
 
 /* new — diagnostic: STREAM-style copy dst[i] = src[i], i < n, with the SAME access shape as the
  * step kernel (one 8-byte element per lane, 512 B per wave-instruction, grid sized the same way).

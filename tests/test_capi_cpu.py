@@ -160,18 +160,3 @@ def test_latin_hypercube_is_stratified_and_seeded():
     assert s["r0"].shape == (3, 5000) and s["q"].shape == (2, 5000)
     r0c = np.asarray(prm.default_params("multigas")["r0"])[:, None]
     assert np.all(s["r0"] >= 0.8 * r0c - 1e-12) and np.all(s["r0"] <= 1.2 * r0c + 1e-12)
-
-
-def test_device_latin_hypercube_design_on_cpu_tensors():
-    """sample_ensemble_device is plain torch: on the CPU device it must give the same DESIGN as the NumPy
-    sampler (one member per stratum, ranges, ECS >= 1.1 TCR, q from k_q); the GPU test repeats this on cuda."""
-    import numpy as np
-    N = 4000
-    base = prm.default_params("multigas")
-    pd = prm.sample_ensemble_device(base, N, "cpu")
-    u = (pd["r0"][0].numpy() / base["r0"][0] - 0.8) / 0.4
-    assert np.array_equal(np.sort(np.floor(u * N).astype(int).clip(0, N - 1)), np.arange(N))
-    tcr, ecs = pd["TCR"].numpy(), pd["ECS"].numpy()
-    assert np.all(ecs >= 1.1 * tcr - 1e-12) and np.all(pd["q"].numpy() > 0)
-    np.testing.assert_allclose(pd["q"].numpy(), prm.k_q(tcr, ecs, base["d"], prm.forcing_2x(base)), rtol=1e-13)
-    assert np.all(pd["rC"][1].numpy() == 0.0)                       # CH4 has no rC term: stays exactly zero

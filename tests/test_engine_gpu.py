@@ -249,12 +249,13 @@ def test_fused_and_graph_paths_are_bit_identical_to_per_step(gpu, kind, G, N, n_
     E = emi.rcp_like_emissions(n_steps, G)
     ref = _engine(p, N, E)
     ref.run(mode="per_step")
-    for mode in ("fused", "graph"):
+    for mode, k in (("fused", None), ("graph", None), ("ksteps", 1), ("ksteps", 7), ("ksteps", 16), ("tiled", 0),
+                    ("tiled", 5), ("auto", None)):
         eng = _engine(p, N, E)
-        eng.run(mode=mode)
+        eng.run(mode=mode, k_steps=k)
         torch.cuda.synchronize()
         for name in ("C", "T", "R", "S"):
-            assert torch.equal(getattr(eng, name), getattr(ref, name)), (mode, name)
+            assert torch.equal(getattr(eng, name), getattr(ref, name)), (mode, k, name)
         eng.close()
 
 
@@ -508,6 +509,77 @@ def test_on_device_stats_match_trajectory(gpu, mode, N):
     assert torch.equal(eng2.T_stats, eng.T_stats)
 
 
+@pytest.mark.parametrize("dtype,N", [("f64", 1), ("f64", 1023), ("f64", 1024), ("f64", 1025), ("f64", 70_001),
+                                     ("f32", 300_007)])
+def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
+    """the tiled kernel accumulates T_hist[step][bin] INSIDE the time loop (LDS-privatised,
+    non-zero bins flushed).  (i) bit for bit the histogram fiveeq_hist_rows_* makes of the stored T rows, at ragged
+    sizes, with outliers in the edge bins; (ii) C, T, R, S and the per-wave moments identical to the fused kernel's;
+    (iii) a run that stores NOTHING gives the same histogram; (iv) percentiles read off it lie within one bin
+    width of np.percentile of the ORACLE's T."""
+    n_steps = 90
+    td = torch.float64 if dtype == "f64" else torch.float32
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3) * 1.7              # warmer: T spreads over many bins
+    E[:, 0] = emi.rcp_like_emissions(750, 1)[200:200 + n_steps, 0] * 1.7
+    lo, hi, nb = 0.05, 1.2, 4096                              # tight on purpose: both edge bins collect outliers
+    ref = _engine(p, N, E, dtype=td, collect_stats=True)
+    ref.run(mode="fused")
+    eng = _engine(p, N, E, dtype=td, collect_stats=True, hist=(lo, hi, nb))
+    assert eng.tile_steps() >= 8
+    eng.run(mode="tiled")
+    bare = _engine(p, N, E, dtype=td, store_trajectory=False, hist=(lo, hi, nb))
+    bare.run(0, 40, mode="tiled", k_steps=3)                  # ragged tiles, resumed
+    bare.run(40, n_steps, mode="tiled")
+    strm = _engine(p, N, E, dtype=td, output_steps=[3, 50, n_steps - 1], store_concentrations=False, collect_stats=True,
+                   hist=(lo, hi, nb), hist_ring_steps=7)      # streamed pipeline: fused kernel + ring + second stream
+    strm.run(0, 33, mode="fused")
+    strm.run(33, n_steps, mode="fused")                        # resumed mid-chunk
+    pers = _engine(p, N, E, dtype=td, output_steps=[3, 50], store_concentrations=False, collect_stats=True,
+                   hist=(lo, hi, nb), chunk_members=256 if N > 600 else 0)     # per-step kernel + histogram of each row
+    pers.run(mode="per_step")
+    torch.cuda.synchronize()
+    for name in ("C", "T", "R", "S", "T_stats"):
+        assert torch.equal(getattr(eng, name), getattr(ref, name)), name
+    want = ref.T_histogram(lo, hi, nb)
+    assert torch.equal(pers.T_hist, want) and torch.equal(pers.T, ref.T[[3, 50]]) and torch.equal(pers.T_stats, ref.T_stats)
+    assert torch.equal(eng.T_hist, want)
+    assert torch.equal(strm.T_hist, want) and torch.equal(strm.T, ref.T[[3, 50, n_steps - 1]])
+    assert torch.equal(strm.R, ref.R) and torch.equal(strm.T_stats, ref.T_stats)
+    assert torch.equal(bare.T_hist, want) and torch.equal(bare.R, ref.R)
+    assert eng.T_hist.sum(1).tolist() == [N] * n_steps
+    assert int(want[-1, 0]) + int(want[-1, -1]) > 0 or N < 100           # the edge bins are exercised
+    if dtype == "f64" and N >= 1000:
+        from fiveeqscm_amd.distributed import histogram_percentiles
+        wide = _engine(p, N, E, store_trajectory=False, hist=(-2.0, 12.0, nb))
+        wide.run(mode="tiled")
+        torch.cuda.synchronize()
+        T_or = c_oracle.run(E, p, N, n_threads=4)["T"]
+        hp, tot = histogram_percentiles(wide.T_hist, -2.0, 12.0, (5.0, 50.0, 95.0))
+        assert tot.tolist() == [float(N)] * n_steps
+        # within one bin width (14 K / 4096) of the exact percentile wherever the sample itself resolves a bin
+        # (neighbouring order statistics closer than a bin: true for N >= 50k except in the outermost tail)
+        tol = 14.0 / nb * (1.0 if N >= 50_000 else 4.0)
+        assert np.abs(hp.cpu().numpy() - np.percentile(T_or, (5.0, 50.0, 95.0), axis=1).T).max() < tol
+
+
+def test_in_loop_histogram_survives_many_blocks_per_workgroup(gpu):
+    """More than 63 member blocks per persistent workgroup (one workgroup per CU: > CUs x 63 x 1024 = 16.5M members)
+    forces the intermediate LDS flush of the packed 16-bit counters; a 1-bin histogram concentrates every member
+    of a workgroup in ONE counter — the worst case for overflow.  Parameters are drawn on the device
+    (sample_ensemble_shard), so nothing of size N touches the host."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    N, n_steps = cus * 64 * 1024 + 5000, 5
+    p = prm.sample_ensemble_shard(prm.default_params("co2"), N, device="cuda:0", dtype=torch.float32)
+    E = emi.rcp_like_emissions(n_steps, 1) + 3.0
+    for nb in (1, 2, 4096):
+        eng = _engine(p, N, E, dtype=torch.float32, store_trajectory=False, hist=(-1.0, 1.0, nb))
+        eng.run(mode="tiled")
+        torch.cuda.synchronize()
+        assert eng.T_hist.sum(1).tolist() == [N] * n_steps, nb
+        del eng
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_histogram_kernel_and_percentiles(gpu, dtype):
     """fiveeq_hist_rows: exact counts against NumPy (edge clamping, ragged chunk, NaN skipped, accumulation
@@ -588,30 +660,24 @@ def test_inverse_mode_matches_oracle_and_round_trips(gpu, kind, G, N):
 
 
 def test_device_side_latin_hypercube(gpu):
-    """params.sample_ensemble_device: stratified, in range, ECS >= 1.1 TCR, q = k_q(TCR, ECS); an engine built
-    from the device tensors equals one built from their host copies."""
+    """fiveeq_lhs_rows_f64 (the kernel) against params.lhs_rows (the NumPy twin) BIT FOR BIT, on a shard of a
+    larger design; params.sample_ensemble_shard on the device == on the host bit for bit; an engine built from the
+    device tensors equals one built from their host copies."""
+    for N, lo, hi in ((1, 0, 1), (1000, 0, 1000), (10_000_000, 3_750_000, 3_750_000 + 70_001),
+                      (100_000_000, 99_900_000, 100_000_000)):
+        got = prm.lhs_rows_device(N, range(11), lo, hi, "cuda:0").cpu().numpy()
+        assert np.array_equal(got, prm.lhs_rows(N, range(11), lo, hi)), N
     N = 50_000
     base = prm.default_params("multigas")
-    pd = prm.sample_ensemble_device(base, N, "cuda:0")
-    for name, lo, hi in (("r0", 0.8, 1.2), ("rC", 0.5, 1.5), ("rT", 0.5, 1.5)):
-        x = pd[name].cpu().numpy()
-        c = np.asarray(base[name], dtype=np.float64)[:, None]
-        assert x.shape == (3, N)
-        for g in range(3):
-            if c[g, 0] == 0:
-                assert np.all(x[g] == 0)
-                continue
-            u = (x[g] / c[g, 0] - lo) / (hi - lo)
-            assert np.array_equal(np.sort(np.floor(u * N).astype(np.int64).clip(0, N - 1)), np.arange(N))   # one per stratum
-    tcr, ecs = pd["TCR"].cpu().numpy(), pd["ECS"].cpu().numpy()
-    assert np.all(ecs >= 1.1 * tcr - 1e-12) and tcr.min() >= 1.0 and ecs.max() <= 4.5
-    np.testing.assert_allclose(pd["q"].cpu().numpy(), prm.k_q(tcr, ecs, base["d"], prm.forcing_2x(base)), rtol=1e-13)
-    assert torch.equal(pd["r0"], prm.sample_ensemble_device(base, N, "cuda:0")["r0"])          # seeded
+    pd = prm.sample_ensemble_shard(base, 4 * N, N, 2 * N, device="cuda:0")
+    ph = prm.sample_ensemble_shard(base, 4 * N, N, 2 * N)
+    for name in ("r0", "rC", "rT", "q", "TCR", "ECS"):
+        assert np.array_equal(pd[name].cpu().numpy(), ph[name]), name
+    full = prm.sample_ensemble_shard(base, N, device="cuda:0")
+    u = ((full["r0"][0] / base["r0"][0] - 0.8) / 0.4).cpu().numpy()
+    assert np.array_equal(np.sort(np.floor(u * N + 1e-9).astype(np.int64).clip(0, N - 1)), np.arange(N))   # one per stratum
     E = emi.rcp_like_emissions(60, 3)
     a = _engine(pd, N, E)
-    ph = dict(pd)
-    for k in ("r0", "rC", "rT", "q"):
-        ph[k] = pd[k].cpu().numpy()
     b = _engine(ph, N, E)
     a.run(mode="fused")
     b.run(mode="fused")

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Cost of in-loop histograms: the time-tiled persistent kernel with T_hist against the
+stats-only fused run of the same ensemble, no trajectory stored.  Also the K-steps-per-launch form on the small
+CO2-only ensemble (BASELINE configs[1]).
+
+    python tools/tiled_hist_bench.py [--members 12500000] [--dtype f32] [--steps 750] [--reps 3]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fiveeqscm_amd import emissions, params  # noqa: E402
+from fiveeqscm_amd.engine import EnsembleEngine  # noqa: E402
+
+
+def timed(eng, reps, **kw):
+    best = None
+    for _ in range(reps + 1):                      # first pass warms clocks / code objects
+        eng.reset_state()
+        if eng.T_hist is not None:
+            eng.T_hist.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run(**kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--members", type=int, default=12_500_000)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--steps", type=int, default=750)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--kind", default="multigas")
+    ap.add_argument("--small", action="store_true", help="also run the config-2 K-steps sweep")
+    a = ap.parse_args()
+    dt = torch.float32 if a.dtype == "f32" else torch.float64
+    G = 3 if a.kind == "multigas" else 1
+    N = a.members
+    p = params.sample_ensemble_shard(params.default_params(a.kind), N, device="cuda:0", dtype=dt)
+    E = emissions.rcp_like_emissions(a.steps, G)
+    base = EnsembleEngine(p, N, E, dtype=dt, store_trajectory=False, collect_stats=True)
+    t_fused = timed(base, a.reps, mode="fused")
+    print(f"{N} members {a.dtype} {a.steps} steps, no trajectory, stats on")
+    print(f"  fused (stats only)            {t_fused / a.steps * 1e6:9.2f} us/step  {N * a.steps / t_fused:.3e} member-steps/s")
+    t_tile0 = timed(base, a.reps, mode="tiled")
+    print(f"  tiled K={base.tile_steps():2d} (stats, no hist)  {t_tile0 / a.steps * 1e6:9.2f} us/step  "
+          f"{t_tile0 / t_fused - 1:+.1%} vs fused")
+    del base
+    for nb in (4096, 1024):
+        eng = EnsembleEngine(p, N, E, dtype=dt, store_trajectory=False, collect_stats=True, hist=(-2.0, 12.0, nb))
+        for k in (0, 8):
+            if k > eng.tile_steps():
+                continue
+            t = timed(eng, a.reps, mode="tiled", k_steps=k)
+            kk = k or eng.tile_steps()
+            print(f"  tiled K={kk:2d} hist {nb:4d} bins        {t / a.steps * 1e6:9.2f} us/step  {t / t_fused - 1:+.1%} vs fused"
+                  f"   A_tile = {eng.bytes_per_member_step('tiled', kk):.1f} B/member-step")
+        assert eng.T_hist.sum(1).min().item() == N
+        for S in (8, 16, 32):
+            eng.hist_ring_steps, eng._ring = S, None
+            t = timed(eng, a.reps, mode="fused")
+            print(f"  fused + streamed hist {nb:4d} bins, ring 2x{S:2d} steps {t / a.steps * 1e6:9.2f} us/step  "
+                  f"{t / t_fused - 1:+.1%} vs fused   ring {2 * S * N * (4 if a.dtype == 'f32' else 8) / 1e9:.2f} GB")
+        assert eng.T_hist.sum(1).min().item() == N
+        del eng
+    if a.small:
+        N2 = 10_000
+        p2 = params.sample_ensemble_shard(params.default_params("co2"), N2)
+        E2 = emissions.rcp_like_emissions(750, 1)
+        eng = EnsembleEngine(p2, N2, E2)
+        print(f"config 2: {N2} members CO2-only fp64, trajectories stored; auto_k_steps = {eng.auto_k_steps()}")
+        for mode, k in (("per_step", None), ("graph", None), ("ksteps", 2), ("ksteps", 4), ("ksteps", 8), ("ksteps", 16),
+                        ("ksteps", 32), ("auto", None), ("fused", None)):
+            t = timed(eng, 5, mode=mode, k_steps=k)
+            print(f"  {mode:8s} K={str(k):4s} {t / 750 * 1e6:7.3f} us/step  {N2 * 750 / t:.3e} member-steps/s")
+
+
+if __name__ == "__main__":
+    main()
