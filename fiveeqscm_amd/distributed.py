@@ -5,9 +5,11 @@ GPU / process, and time-stepping needs NO communication.  The only exchange is a
 step: summary statistics of T (or C) at selected output times, over ALL members —
   * moments (count, mean, variance, min, max): each rank reduces its shard, the tiny per-rank
     records are all-gathered and merged with Chan's parallel-variance formula;
-  * exact percentiles: each rank's rows are gathered to one root (on an 8-GPU MI355X node the
-    root receives over all 7 of its xGMI links at once; 10 MB per rank and output time at
-    1.25M members), sorted there, and read off with NumPy's default linear interpolation.
+  * exact percentiles by SELECTION, not by sorting the ensemble: a 16384-bin histogram per output time
+    between the global min and max is all-reduced (0.4 MB per rank for three output times), the bins
+    holding the wanted order statistics are located on its cumulative counts, and only the members
+    inside those bins travel to the root (a few thousand values out of 10M), where they are sorted
+    and read off with NumPy's default linear interpolation.  Values keep their dtype on the wire.
 `torch.distributed` backend "nccl" is RCCL on ROCm; the same code runs on CPU tensors over gloo
 (tests/test_distributed.py).  The reference has no distributed code at all.
 """
@@ -38,14 +40,18 @@ def _comm_tensor(dist, group, x):
     return x
 
 
-def local_moments(x):
-    """x [K, n] -> [K, 5] = (count, mean, M2, min, max) per row, in fp64."""
-    x = x.to(torch.float64)
-    n = x.shape[1]
-    mean = x.mean(dim=1)
-    m2 = ((x - mean[:, None]) ** 2).sum(dim=1)
+def local_moments(x, chunk=1 << 22):
+    """x [K, n] -> [K, 5] = (count, mean, M2, min, max) per row; fp64 accumulation without an fp64 copy
+    of the rows (chunks of 4M members)."""
+    K, n = x.shape
+    mean = x.sum(dim=1, dtype=torch.float64) / n
+    m2 = torch.zeros(K, dtype=torch.float64, device=x.device)
+    for c0 in range(0, n, chunk):
+        d = x[:, c0:c0 + chunk].to(torch.float64) - mean[:, None]
+        m2 += (d * d).sum(dim=1)
     cnt = torch.full_like(mean, float(n))
-    return torch.stack([cnt, mean, m2, x.min(dim=1).values, x.max(dim=1).values], dim=1)
+    return torch.stack([cnt, mean, m2, x.min(dim=1).values.to(torch.float64), x.max(dim=1).values.to(torch.float64)],
+                       dim=1)
 
 
 def merge_moments(parts):
@@ -123,36 +129,102 @@ def histogram_percentiles(hist, lo, hi, percentiles=(5.0, 50.0, 95.0), group=Non
     return torch.stack(cols, dim=1), total
 
 
-def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None):
+SELECT_BINS = 16384
+
+
+def _bin_index(x, lo, scale, n_bins):
+    """Bin of every value: floor((x - lo) * scale) clipped to [0, n_bins).  Used for BOTH the histogram and the
+    candidate selection, so the two are consistent by construction.  fp64 arithmetic, chunk-free view ops."""
+    idx = ((x.to(torch.float64) - lo[:, None]) * scale[:, None]).floor_().clamp_(0, n_bins - 1)
+    return idx.to(torch.int64)
+
+
+def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None, n_bins=SELECT_BINS, stats=None):
+    """Exact percentiles (NumPy 'linear' definition) of rows [K, n_local] over all ranks by histogram selection.
+    gmin/gmax [K] fp64: global extrema (from the merged moments); n_total: members over all ranks.
+    Returns [K, P] fp64 on rank `dst`, None elsewhere.  `stats`, if a dict, receives bytes_to_root."""
+    dist, rank, world = _dist(group)
+    K, n_local = rows.shape
+    P = len(percentiles)
+    dev = rows.device
+    span = gmax - gmin
+    scale = torch.where(span > 0, n_bins / span.clamp_min(1e-300), torch.zeros_like(span))
+    idx = _bin_index(rows, gmin, scale, n_bins)                                    # [K, n_local]
+    counts = torch.zeros((K, n_bins), dtype=torch.int64, device=dev)
+    counts.scatter_add_(1, idx, torch.ones_like(idx))
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    cdf = torch.cumsum(counts, dim=1)                                              # [K, n_bins], last = n_total
+    pos = torch.tensor([float(p) / 100.0 * (n_total - 1) for p in percentiles], dtype=torch.float64, device=dev)
+    i0 = pos.floor().to(torch.int64)                                               # [P] order-statistic indices
+    i1 = (i0 + 1).clamp_(max=n_total - 1)
+    frac = pos - i0.to(torch.float64)
+    want = torch.stack([i0, i1], dim=1).reshape(1, 2 * P).expand(K, 2 * P).contiguous()
+    b = torch.searchsorted(cdf, want, right=True).clamp_(max=n_bins - 1)           # first bin with cdf > index
+    b0, b1 = b[:, 0::2], b[:, 1::2]                                                # [K, P]
+    below = torch.where(b0 > 0, cdf.gather(1, (b0 - 1).clamp_(min=0)), torch.zeros_like(b0))
+    # this rank's members inside [b0, b1] for every (row, percentile): one flat payload + its size table
+    parts, sizes = [], []
+    for k in range(K):
+        for j in range(P):
+            sel = rows[k][(idx[k] >= b0[k, j]) & (idx[k] <= b1[k, j])]
+            parts.append(sel)
+            sizes.append(sel.numel())
+    payload = torch.cat(parts) if parts else rows.new_empty(0)
+    size_t = torch.tensor(sizes, dtype=torch.int64, device=dev)
+    if world > 1:
+        all_sizes = [torch.empty_like(size_t) for _ in range(world)]
+        dist.all_gather(all_sizes, size_t, group=group)
+        all_sizes = torch.stack(all_sizes).cpu()                                   # [world, K*P]
+        longest = int(all_sizes.sum(dim=1).max().item())
+        send = torch.cat([payload, payload.new_zeros(longest - payload.numel())])
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, recv, dst=dst, group=group)
+        if stats is not None:
+            stats["bytes_to_root"] = int((all_sizes.sum() - all_sizes[dst].sum()).item()) * payload.element_size()
+            stats["allreduce_bytes"] = counts.numel() * 8            # the histogram every rank contributes
+        if rank != dst:
+            return None
+        offs = torch.cat([torch.zeros((world, 1), dtype=torch.int64), all_sizes.cumsum(dim=1)], dim=1)
+        cand = [[torch.cat([recv[w][offs[w, q]:offs[w, q + 1]] for w in range(world)]) for q in range(K * P)]]
+        cand = cand[0]
+    else:
+        if stats is not None:
+            stats["bytes_to_root"] = 0
+            stats["allreduce_bytes"] = 0
+        offs = [0]
+        for n_q in sizes:
+            offs.append(offs[-1] + n_q)
+        cand = [payload[offs[q]:offs[q + 1]] for q in range(K * P)]
+    out = torch.empty((K, P), dtype=torch.float64, device=dev)
+    below_h, i0_h, i1_h, frac_h = below.cpu(), i0.cpu(), i1.cpu(), frac.cpu()
+    for k in range(K):
+        for j in range(P):
+            c, _ = torch.sort(cand[k * P + j].to(torch.float64))
+            lo_i = int(i0_h[j] - below_h[k, j])
+            hi_i = int(i1_h[j] - below_h[k, j])
+            if not (0 <= lo_i <= hi_i < c.numel()):
+                raise RuntimeError(f"percentile selection lost its order statistic (row {k}, p={percentiles[j]}): "
+                                   f"{lo_i},{hi_i} of {c.numel()} candidates")
+            out[k, j] = c[lo_i] + (c[hi_i] - c[lo_i]) * float(frac_h[j])
+    return out
+
+
+def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats=None):
     """rows [K, n_local]: this rank's members at K output times.  Collective over `group`.
     Returns on every rank a dict with the merged moments (mean, var, min, max, count; [K] each, fp64);
-    on rank `dst` it also holds 'percentiles' [K, len(percentiles)] over ALL members (None elsewhere)."""
+    on rank `dst` it also holds 'percentiles' [K, len(percentiles)] over ALL members (None elsewhere) —
+    exact (NumPy 'linear'), found by selection (see the module docstring).  `stats` (dict) receives
+    'bytes_to_root' (candidate members the root received) and 'allreduce_bytes' (the histogram)."""
     dist, rank, world = _dist(group)
     rows = _comm_tensor(dist, group, rows.contiguous())
-    K, n_local = rows.shape
     mom = local_moments(rows)
     if world > 1:
         parts = [torch.empty_like(mom) for _ in range(world)]
         dist.all_gather(parts, mom, group=group)
         mom = merge_moments(torch.stack(parts))
-        # shard sizes may differ by one: pad to the largest with +inf (sorts to the end, then dropped)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=rows.device) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([n_local], dtype=torch.int64, device=rows.device), group=group)
-        sizes = [int(s.item()) for s in sizes]
-        n_max = max(sizes)
-        send = rows if n_local == n_max else torch.cat(
-            [rows, torch.full((K, n_max - n_local), float("inf"), dtype=rows.dtype, device=rows.device)], dim=1)
-        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-        dist.gather(send, recv, dst=dst, group=group)
-        if rank == dst:
-            allrows = torch.cat([r[:, :s] for r, s in zip(recv, sizes)], dim=1)
-        else:
-            allrows = None
-    else:
-        allrows = rows
+    n_total = int(round(float(mom[0, 0].item())))
     out = {"count": mom[:, 0], "mean": mom[:, 1], "var": mom[:, 2] / mom[:, 0], "min": mom[:, 3], "max": mom[:, 4],
-           "percentiles": None}
-    if allrows is not None:
-        xs, _ = torch.sort(allrows.to(torch.float64), dim=1)
-        out["percentiles"] = percentiles_sorted(xs, percentiles)
+           "percentiles": exact_percentiles(rows, percentiles, mom[:, 3], mom[:, 4], n_total, dst=dst, group=group,
+                                            stats=stats)}
     return out

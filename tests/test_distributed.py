@@ -123,3 +123,70 @@ def test_gloo_world2_summary_exchange(n_total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(results)
+
+
+def test_selection_percentiles_edge_cases():
+    """exact_percentiles: ties, constant rows, tiny rows, fp32 rows kept in fp32 on the wire."""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 5, 1000, 200_001):
+        x = np.stack([rng.normal(size=n), rng.uniform(size=n) ** 3, np.full(n, 2.5), np.round(rng.normal(size=n), 1)])
+        for dt in (np.float64, np.float32):
+            xs = x.astype(dt)
+            st = {}
+            out = gather_summary(torch.from_numpy(xs), (0.0, 5.0, 50.0, 95.0, 100.0, 33.3), stats=st)
+            want = np.percentile(xs.astype(np.float64), (0.0, 5.0, 50.0, 95.0, 100.0, 33.3), axis=1).T
+            np.testing.assert_allclose(out["percentiles"].numpy(), want, rtol=1e-14, atol=0)
+            assert st["bytes_to_root"] == 0
+
+
+# ---- BASELINE configs[3] rehearsed at world size 8 (CPU, gloo): every rank computes ONLY its shard of the
+# shard-computable Latin hypercube, advances it with the C oracle (no GPU here), and the summary exchange must
+# reproduce np.percentile / mean of the ORACLE's T over the whole ensemble computed in one piece. -------------
+N8, STEPS8, YEARS8 = 40_003, 110, [30, 70, 109]
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    import torch.distributed as dist
+    from fiveeqscm_amd import emissions, params
+    from oracle import c_oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        base = params.default_params("multigas")
+        E = emissions.rcp_like_emissions(750, 3)[200:200 + STEPS8]
+        lo, hi = shard_bounds(N8, rank, world)
+        mine = params.sample_ensemble_shard(base, N8, lo, hi)                 # O(shard): nothing of size N8 here
+        T = c_oracle.run(E, mine, hi - lo, keep=("T",))["T"]
+        st = {}
+        s = gather_summary(torch.from_numpy(np.ascontiguousarray(T[YEARS8])), percentiles=(5.0, 50.0, 95.0), stats=st)
+        if rank == 0:
+            whole = params.sample_ensemble_shard(base, N8)
+            Tw = c_oracle.run(E, whole, N8, keep=("T",), n_threads=4)["T"][YEARS8]
+            ok = (np.allclose(s["percentiles"].numpy(), np.percentile(Tw, (5.0, 50.0, 95.0), axis=1).T, rtol=1e-13)
+                  and np.allclose(s["mean"].numpy(), Tw.mean(1), rtol=1e-13)
+                  and np.allclose(s["var"].numpy(), Tw.var(1), rtol=1e-11)
+                  and np.array_equal(s["min"].numpy(), Tw.min(1)) and np.array_equal(s["max"].numpy(), Tw.max(1))
+                  and s["count"].tolist() == [float(N8)] * 3
+                  and st["bytes_to_root"] < 0.05 * 3 * N8 * 8)                # a few % of gathering the rows
+            q.put(bool(ok))
+        else:
+            q.put(s["percentiles"] is None)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world8_config4_rehearsal_against_the_oracle():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(results)

@@ -287,17 +287,28 @@ def test_checkpoint_state_dict_roundtrip(gpu, tmp_path):
     N, n_steps = 500, 90
     p = prm.sample_ensemble(prm.default_params("multigas"), N)
     E = emi.rcp_like_emissions(n_steps, 3)
-    whole = _engine(p, N, E)
-    whole.run()
-    first = _engine(p, N, E)
-    first.run(0, 33)
-    np.savez(tmp_path / "ck.npz", **first.state_dict())
-    second = _engine(p, N, E)
+    kw = dict(collect_stats=True, hist=(-1.0, 4.0, 512))
+    whole = _engine(p, N, E, **kw)
+    whole.run(mode="tiled")
+    first = _engine(p, N, E, **kw)
+    first.run(0, 33, mode="tiled")
+    ck = first.state_dict()
+    assert ck["t_next"] == 33
+    np.savez(tmp_path / "ck.npz", **ck)
+    second = _engine(p, N, E, **kw)
     second.load_state_dict(dict(np.load(tmp_path / "ck.npz")))
-    second.run(33, n_steps, mode="fused")
+    assert second.t_next == 33
+    second.run(second.t_next, n_steps, mode="tiled")
     torch.cuda.synchronize()
     assert torch.equal(second.R, whole.R) and torch.equal(second.S, whole.S)
-    assert torch.equal(second.T[33:], whole.T[33:]) and torch.equal(second.C[33:], whole.C[33:])
+    # the checkpoint carries what the run had accumulated: ALL rows, moments and histograms equal an uninterrupted run
+    assert torch.equal(second.T, whole.T) and torch.equal(second.C, whole.C)
+    assert torch.equal(second.T_stats, whole.T_stats) and torch.equal(second.T_hist, whole.T_hist)
+    bare = _engine(p, N, E)
+    bare.load_state_dict(first.state_dict(include_outputs=False))      # state only: later rows still right
+    bare.run(33, n_steps, mode="fused")
+    torch.cuda.synchronize()
+    assert torch.equal(bare.T[33:], whole.T[33:]) and torch.equal(bare.C[33:], whole.C[33:])
     with pytest.raises(ValueError):
         second.load_state_dict({"R": np.zeros((2, 2)), "S": np.zeros((2, N))})
 
@@ -542,7 +553,11 @@ def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
     for name in ("C", "T", "R", "S", "T_stats"):
         assert torch.equal(getattr(eng, name), getattr(ref, name)), name
     want = ref.T_histogram(lo, hi, nb)
-    assert torch.equal(pers.T_hist, want) and torch.equal(pers.T, ref.T[[3, 50]]) and torch.equal(pers.T_stats, ref.T_stats)
+    assert torch.equal(pers.T_hist, want) and torch.equal(pers.T, ref.T[[3, 50]])
+    # the per-step kernel folds a wave's moments with the DPP ladder, the fused/tiled kernels with the LDS transpose:
+    # same numbers, different summation order (min/max exact, sums to rounding)
+    assert torch.equal(pers.T_stats[..., 2:], ref.T_stats[..., 2:])
+    assert torch.allclose(pers.T_stats[..., :2], ref.T_stats[..., :2], rtol=1e-12, atol=0)
     assert torch.equal(eng.T_hist, want)
     assert torch.equal(strm.T_hist, want) and torch.equal(strm.T, ref.T[[3, 50, n_steps - 1]])
     assert torch.equal(strm.R, ref.R) and torch.equal(strm.T_stats, ref.T_stats)
@@ -884,3 +899,50 @@ def test_full_size_config3_direct_parity_of_final_state(gpu):
     _close(eng.T[0], T_end, what="T final")
     st = eng.stats()
     assert abs(st["mean"][749].item() - T_end.mean()) < 1e-12 and st["max"][749].item() == eng.T[0].max().item()
+
+
+def _host_threads():
+    import os
+    threads = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            threads = max(1, min(threads, int(int(quota) / int(period))))
+    except OSError:
+        pass
+    return min(threads, 64)
+
+
+@pytest.mark.parametrize("chunk", [0, 262144])
+def test_full_size_config4_shard_rank3_of_8(gpu, chunk):
+    """BASELINE configs[3]: the 10M-member multi-gas ensemble over 8 GPUs.  This is rank 3's actual shard — members
+    [3.75M, 5M) of the shard-computable 10M-member Latin hypercube, drawn on the device — at full size, fp64, 750 steps,
+    with the chunk-major schedule off and on: final pools, thermal boxes and T of all 1.25M DISTINCT members against
+    the C oracle run on the host twin of the same design."""
+    from fiveeqscm_amd.distributed import shard_bounds
+    N_total, n_steps = 10_000_000, 750
+    lo, hi = shard_bounds(N_total, 3, 8)
+    N = hi - lo
+    assert N == 1_250_000
+    base = prm.default_params("multigas")
+    pd = prm.sample_ensemble_shard(base, N_total, lo, hi, device="cuda:0")
+    ph = dict(pd)
+    for k in ("r0", "rC", "rT", "q"):
+        ph[k] = pd[k].cpu().numpy()
+    E = emi.rcp_like_emissions(n_steps, 3)
+    want = c_oracle.run(E, ph, N, n_threads=_host_threads(), keep=())
+    eng = _engine(pd, N, E, output_steps=[249, 499, 749], collect_stats=True, chunk_members=chunk)
+    assert len(eng._chunks()) == (1 if not chunk else 5)
+    eng.run()
+    torch.cuda.synchronize()
+    _close(eng.R, want["R"], atol=1e-12, what="R final")
+    _close(eng.S, want["S"], what="S final")
+    T_end = want["S"][0] + want["S"][1]
+    _close(eng.T[2], T_end, what="T final")
+    st = eng.stats()
+    assert abs(st["mean"][749].item() - T_end.mean()) < 1e-12 and st["count"][0].item() == float(N)
+    # the percentile exchange of this shard alone (world size 1): exact against NumPy on the oracle's T
+    from fiveeqscm_amd.distributed import gather_summary
+    s = gather_summary(eng.T[2:3], percentiles=(5.0, 50.0, 95.0))
+    np.testing.assert_allclose(s["percentiles"].cpu().numpy()[0], np.percentile(T_end, (5.0, 50.0, 95.0)), rtol=1e-10)
