@@ -9,16 +9,20 @@ A "step" is ONE MODEL TIMESTEP of the whole ensemble = one launch of the per-tim
 (fiveeq_step_f64, include/fiveeq.h) on each GPU.  Workload (BASELINE.json configs[2], the
 largest single-GPU configuration and the one the roofline target is quoted for): 1,000,000
 members per GPU (weak scaling), CO2+CH4+N2O, fp64, deterministic RCP-like emissions
-(SURVEY.md section 8d), Latin-hypercube parameter draws (seed 20261003), state and parameters
-resident in HBM, C/T trajectory rows written every step.  Timesteps cycle through the 750-step
-scenario (t = k mod 750); the default K + W = 750 is exactly one scenario pass.
+(SURVEY.md section 8d), Latin-hypercube parameter draws (seed 20261003; the shard-computable design:
+every rank draws exactly its own members on its own GPU), state and parameters resident in HBM, C/T
+trajectory rows written every step.  Timesteps cycle through the 750-step scenario (t = k mod 750); the
+default K + W = 750 is exactly one scenario pass.
 
 Rank 0 prints ONE JSON line.  `value` = (members on all GPUs) x K / max-over-ranks wall time of
-the K timed steps.  `roofline` prices the per-step kernel against the 8 TB/s HBM peak with the
-ALGORITHMIC bytes A = w(2 SP + 4 G + 7) = 248 B per member-step; `cpu_baseline` times the CPU
-oracle (plain-C port, OpenMP) on this box's host cores on a bounded sample (rank 0, N=1 only).
+the K timed steps.  `roofline` prices the kernel of the chosen --mode: the per-step kernel against the
+8 TB/s HBM peak with the ALGORITHMIC bytes A = w(2 SP + 4 G + 7) = 248 B per member-step (plus the same
+kernel on an ensemble far beyond the Infinity Cache, `hbm_resident`, and its fp64 VALU issue fraction);
+the fused / K-step kernels with their own A and bound "fp64-valu".  `cpu_baseline` times the CPU oracle
+(plain-C port, OpenMP) on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -32,6 +36,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# Vector issue peak: 256 CUs x 4 SIMDs at 2.4 GHz.  A wave64 fp64 instruction occupies its SIMD for 4 cycles
+# (16 FMA lanes per clock: 78.6 TFLOP/s fp64 vector, the datasheet figure) -> 6.144e11 wave-instructions/s; a wave64
+# fp32 instruction for 2 (32 lanes per clock: 157.3 TFLOP/s fp32 vector) -> 1.229e12.  Integer / conversion / select
+# instructions in the stream are priced like the kernel's float type: an estimate, stated as such.
+SIMDS = 1024
+CLOCK_HZ = 2.4e9
+VALU_CYCLES_PER_INSTR = {"f64": 4.0, "f32": 2.0}
 
 WORKLOADS = {
     # name: (param set, gases, members per GPU, description)
@@ -50,21 +61,24 @@ def parse():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--members", type=int, default=0, help="members per GPU (default: the workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--mode", default="per_step", choices=["per_step", "graph", "fused"])
+    ap.add_argument("--mode", default="per_step", choices=["per_step", "graph", "fused", "ksteps", "auto", "tiled"])
+    ap.add_argument("--k-steps", type=int, default=0, help="steps per launch for --mode ksteps/tiled (0: the engine's choice)")
     ap.add_argument("--no-trajectory", action="store_true", help="do not store C/T rows (drops G+1 writes from A)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-resident", action="store_true", help="skip the beyond-Infinity-Cache roofline leg")
+    ap.add_argument("--hbm-resident-members", type=int, default=8_000_000)
     ap.add_argument("--cpu-sample-members", type=int, default=1_500_000)
     ap.add_argument("--kernel-batches", type=int, default=5, help="event-timed batches of 100 launches for roofline")
     return ap.parse_args()
 
 
-def run_steps(eng, t0, k, mode):
+def run_steps(eng, t0, k, mode, k_steps):
     """Advance k model timesteps starting at scenario index t0 (cycling); returns the next index."""
     n = eng.n_steps
     t = t0 % n
     while k > 0:
         seg = min(k, n - t)
-        eng.run(t, t + seg, mode=mode)
+        eng.run(t, t + seg, mode=mode, k_steps=k_steps)
         k -= seg
         t = (t + seg) % n
     return t
@@ -133,6 +147,34 @@ def cpu_baseline(kind, G, n_sample, n_steps):
     }
 
 
+def event_timed(eng, launch, t_idx, n_scen, span, batches):
+    """Average duration of one `launch(t, t + span)` (HIP events on the launch stream, queue kept busy ahead of the
+    first event): list of per-launch-unit seconds, one per batch."""
+    samples = []
+    lead = min(5, max(1, span))
+    for i in range(max(batches, 1)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t = (t_idx + i * span) % max(1, n_scen - span - lead)          # t + lead + span <= n_scen always
+        launch(t, t + lead)                                             # keep the queue busy ahead of the first event
+        e0.record()
+        launch(t + lead, t + lead + span)
+        e1.record()
+        e1.synchronize()
+        samples.append(e0.elapsed_time(e1) * 1e-3)
+    return np.array(samples)
+
+
+def load_profile_json(name, key):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(key)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,16 +208,17 @@ def main():
     n_total = per_gpu * world
     n_scen = 750
     dtype = torch.float64 if a.dtype == "f64" else torch.float32
+    k_steps = a.k_steps or None
 
-    # global Latin hypercube over ALL members; this rank keeps its contiguous shard
+    # This rank's contiguous shard [lo, hi) of ONE Latin hypercube over all members, drawn on this
+    # rank's GPU: O(shard) work and memory whatever the world size, identical design for any world size.
+    t_setup = time.perf_counter()
     lo, hi = shard_bounds(n_total, rank, world)
-    full = params.sample_ensemble(params.default_params(kind), n_total)
-    p = dict(full)
-    for k in ("r0", "rC", "rT", "q"):
-        p[k] = np.ascontiguousarray(full[k][:, lo:hi])
-    del full
+    p = params.sample_ensemble_shard(params.default_params(kind), n_total, lo, hi, device=dev, dtype=dtype)
     E = emissions.rcp_like_emissions(n_scen, G)
     eng = EnsembleEngine(p, hi - lo, E, dtype=dtype, device=dev, store_trajectory=not a.no_trajectory)
+    torch.cuda.synchronize(dev)
+    setup_s = time.perf_counter() - t_setup
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -183,9 +226,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # ---- device spin-up (not model work): the host spent seconds building parameters while the GPU idled
-    # at its lowest clock; ~30 ms of a plain copy kernel brings it back so that a small W is enough ----
-    import ctypes
+    # ---- device spin-up (not model work): the GPU idles at its lowest clock during host set-up;
+    # ~30 ms of a plain copy kernel brings it back so that a small W is enough ----
     spin_src = torch.empty(1 << 25, dtype=torch.float64, device=dev).normal_()
     spin_dst = torch.empty_like(spin_src)
     for _ in range(256):
@@ -195,7 +237,7 @@ def main():
     del spin_src, spin_dst
 
     # ---- warm-up, then EXACTLY K timed steps ------------------------------------------------------
-    t_idx = run_steps(eng, 0, a.warmup, a.mode)
+    t_idx = run_steps(eng, 0, a.warmup, a.mode, k_steps)
     if a.mode == "graph":                      # instantiate the timed region's graphs outside the timing
         t_probe, k = t_idx % n_scen, a.steps
         while k > 0:
@@ -205,7 +247,7 @@ def main():
             t_probe = (t_probe + seg) % n_scen
     sync_all()
     t0 = time.perf_counter()
-    t_idx = run_steps(eng, t_idx, a.steps, a.mode)
+    t_idx = run_steps(eng, t_idx, a.steps, a.mode, k_steps)
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -214,90 +256,162 @@ def main():
         elapsed = float(tt.item())
     value = n_total * a.steps / elapsed
 
-    # ---- roofline: per-launch duration of the per-step kernel, HIP events on the launch stream ----
-    # The engine launches on torch's current stream, so torch.cuda.Event (hipEvent) brackets the
-    # launches.  Each sample = one batch of `per_batch` launches enqueued back-to-back from C between
-    # two events, divided by per_batch: the queue stays full, so the quotient is the kernel's duration
-    # plus the ~1-2 us dependent-launch boundary (a single bracketed launch would add the ~10 us
-    # idle-stream launch latency instead and overstate the kernel).
-    A = eng.bytes_per_member_step("per_step")
-    n_launch = len(eng._chunks())              # > 1 when the engine schedules chunk-major (large ensembles)
-    members_per_launch = (hi - lo) / n_launch
-    per_batch = 100
-    samples = []
-    for i in range(max(a.kernel_batches, 1)):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t = (t_idx + i * per_batch) % (n_scen - per_batch)
-        eng.run(t, t + 5)                                   # keep the queue busy ahead of the first event
-        e0.record()
-        eng.run(t + 5, t + 5 + per_batch)
-        e1.record()
-        e1.synchronize()
-        samples.append(e0.elapsed_time(e1) * 1e-3 / (per_batch * n_launch))
-    samples = np.array(samples)
-    k_avg = float(samples.mean())
-    achieved = A * members_per_launch / k_avg / 1e9
+    # ---- end-of-run exchange (the only collective): summary statistics of T over all members.  Done NOW, on the
+    # rows the timed pass wrote, before the roofline batches below re-run (and overwrite) scenario steps. ----------
+    summary, summary_error, summary_ms, summary_stats, years = None, None, None, {}, []
+    if eng.T is not None:
+        done = min(a.warmup + a.steps, n_scen)                  # scenario steps the timed run has written
+        years = [t for t in (249, 499, 749) if t < done] or [done - 1]
+        try:
+            rows = eng.T[years]
+            gather_summary(rows, percentiles=(5.0, 50.0, 95.0))        # warm: first-call library/JIT set-up of the ops
+            sync_all()
+            ts = time.perf_counter()
+            summary = gather_summary(rows, percentiles=(5.0, 50.0, 95.0), stats=summary_stats)
+            torch.cuda.synchronize(dev)
+            summary_ms = (time.perf_counter() - ts) * 1e3
+        except Exception as exc:  # noqa: BLE001 - outside the timed region: report it, do not lose the line
+            summary = None
+            summary_error = f"{type(exc).__name__}: {exc}"
+
+    # ---- roofline: per-launch duration of the timed mode's kernel, HIP events on the launch stream ----
+    # The engine launches on torch's current stream, so torch.cuda.Event (hipEvent) brackets the launches.  Each
+    # sample = one batch of launches enqueued back-to-back from C between two events: the queue stays full, so the
+    # quotient is the kernel's duration plus the ~1-2 us dependent-launch boundary (a single bracketed launch would
+    # add the ~10 us idle-stream launch latency instead and overstate the kernel).
+    n_local = hi - lo
+    valu_peak = SIMDS * CLOCK_HZ / VALU_CYCLES_PER_INSTR[a.dtype]
+    tname = "double" if a.dtype == "f64" else "float"
+    pools3 = ",".join(str(x) for x in (eng.pools + [0, 0])[:3])
+    fusedlike = a.mode in ("fused", "ksteps", "tiled") or (a.mode == "auto" and eng.auto_k_steps() > 1)
+    if not fusedlike:
+        A = eng.bytes_per_member_step("per_step")
+        n_launch = len(eng._chunks())          # > 1 when the engine schedules chunk-major (large ensembles)
+        members_per_launch = n_local / n_launch
+        per_batch = 100
+        samples = event_timed(eng, lambda t0_, t1_: eng.run(t0_, t1_), t_idx, n_scen, per_batch, a.kernel_batches)
+        samples = samples / (per_batch * n_launch)
+        k_avg = float(samples.mean())
+        achieved = A * members_per_launch / k_avg / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": (load_profile_json("traffic.json", f"{a.workload}:{a.dtype}:{per_gpu}") or {}).get(
+                        "hbm_bytes_per_launch"),
+                    "kernel": f"fiveeq::step_kernel<{tname},{pools3}>",
+                    "algorithmic_bytes_per_member_step": A, "members_per_launch": members_per_launch,
+                    "algorithmic_bytes_per_launch": A * members_per_launch,
+                    "avg_launch_us": k_avg * 1e6, "min_launch_us": float(samples.min()) * 1e6,
+                    "launches_timed": int(samples.size) * per_batch * n_launch,
+                    "note": "achieved = algorithmic bytes / kernel time.  At 1M members the 152 MB of state + parameters "
+                            "stay in the 256 MiB Infinity Cache between launches, so this is HBM-peak-priced algorithmic "
+                            "traffic, not bytes that crossed HBM; `hbm_resident` is the same kernel with nothing cached."}
+        kkey = f"step:{a.dtype}:{pools3}"
+    else:
+        # the time-fused family: one launch covers `span` steps; price it per step with its own A
+        if a.mode == "tiled":
+            span = k_steps or eng.tile_steps()
+            kname, mode_t = "tile_kernel", "tiled"
+        elif a.mode == "fused":
+            span, kname, mode_t = 100, "fused_kernel", "fused"
+        else:
+            span = k_steps or eng.auto_k_steps()
+            kname, mode_t = "fused_kernel", "ksteps"
+        A = eng.bytes_per_member_step("fused" if a.mode == "fused" else mode_t, None if a.mode == "fused" else span)
+        fn = getattr(eng.lib, f"fiveeq_run_{'fused' if kname == 'fused_kernel' else 'tiled'}_{eng._sfx}")
+
+        def one(t0_, t1_):
+            if kname == "fused_kernel":
+                rc = fn(*eng._run_args(t0_, t1_), eng._stream())
+            else:
+                rc = fn(*eng._run_args(t0_, t1_), t1_ - t0_, 0.0, 1.0, 0, ctypes.c_void_p(0), eng._stream())
+            assert rc == 0, eng.lib.fiveeq_last_error()
+
+        reps = max(1, 100 // span)
+
+        def batch(t0_, t1_):                                    # `reps` launches of `span` steps inside one bracket
+            if t1_ - t0_ < span:
+                one(t0_, t1_)
+                return
+            for _ in range(reps):
+                one(t0_, t0_ + span)
+
+        samples = event_timed(eng, batch, t_idx, n_scen, span, a.kernel_batches) / (reps * span)
+        k_avg = float(samples.mean())                           # seconds per model step inside the kernel
+        achieved = A * n_local / k_avg / 1e9
+        roofline = {"bound": "fp64-valu" if a.dtype == "f64" else "fp32-valu", "unit": "wave-instr/s",
+                    "achieved": None, "peak": valu_peak, "frac": None, "traffic": None,
+                    "kernel": f"fiveeq::{kname}<{tname},{pools3}>", "steps_per_launch": span,
+                    "algorithmic_bytes_per_member_step": A, "members_per_launch": n_local,
+                    "hbm_GBs_of_algorithmic_bytes": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
+                    "avg_step_us_in_kernel": k_avg * 1e6, "launches_timed": int(samples.size) * reps,
+                    "note": "time-fused family: state stays in registers, the kernel is bound by VALU issue, not HBM; "
+                            "frac = VALU wave-instructions per second / (1024 SIMDs x 2.4 GHz / cycles per instruction)."}
+        kkey = f"{'fused' if kname == 'fused_kernel' else 'tile'}:{a.dtype}:{pools3}"
+    # VALU issue: instructions per wave-step from the committed SQ-counter pass (profiles/valu.json, produced by
+    # tools/collect_profiles.sh with rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ...), times the waves this bench ran
+    valu = load_profile_json("valu.json", kkey)
+    if valu:
+        waves = -(-int(roofline["members_per_launch"]) // 64)
+        rate = valu["valu_per_wave_step"] * waves / k_avg
+        issue = {"valu_wave_instr_per_wave_step": valu["valu_per_wave_step"], "wave_instr_per_s": rate,
+                 "peak_wave_instr_per_s": valu_peak, "frac": rate / valu_peak,
+                 "peak_def": f"1024 SIMDs x 2.4 GHz / {VALU_CYCLES_PER_INSTR[a.dtype]:.0f} cycles per wave64 {a.dtype} VALU "
+                             "instruction (78.6 TFLOP/s fp64 / 157.3 TFLOP/s fp32 vector FMA)",
+                 "source": "profiles/valu.json"}
+        if fusedlike:
+            roofline["achieved"], roofline["frac"] = rate, issue["frac"]
+        roofline["fp64_issue_frac" if a.dtype == "f64" else "fp32_issue_frac"] = issue["frac"]
+        roofline["valu_issue"] = issue
+
     # achievable copy bandwidth on this box, same access shape (8 B/lane), buffers beyond the 256 MiB L3
     n_copy = 1 << 27                                        # 1 GiB read + 1 GiB written per launch
     src = torch.empty(n_copy, dtype=torch.float64, device=dev).normal_()
     dst = torch.empty_like(src)
-    cp = lambda: eng.lib.fiveeq_stream_copy_f64(n_copy, ctypes.c_void_p(src.data_ptr()),   # noqa: E731
-                                                ctypes.c_void_p(dst.data_ptr()), eng._stream())
-    for _ in range(3):
-        cp()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        cp()
-    e1.record()
-    e1.synchronize()
-    copy_gbs = 2 * n_copy * 8 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    cpw = lambda: eng.lib.fiveeq_stream_copy_wide_f64(n_copy, ctypes.c_void_p(src.data_ptr()),   # noqa: E731
-                                                      ctypes.c_void_p(dst.data_ptr()), eng._stream())
-    for _ in range(3):
-        cpw()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        cpw()
-    e1.record()
-    e1.synchronize()
-    copy_wide_gbs = 2 * n_copy * 8 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del src, dst
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
-        try:
-            with open(tf) as fh:
-                rec = json.load(fh).get(f"{a.workload}:{a.dtype}:{per_gpu}")
-            traffic = rec["hbm_bytes_per_launch"] if rec else None
-        except Exception:  # noqa: BLE001
-            traffic = None
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": f"fiveeq::step_kernel<{'double' if a.dtype == 'f64' else 'float'},"
-                          f"{','.join(str(x) for x in (eng.pools + [0, 0])[:3])}>",
-                "algorithmic_bytes_per_member_step": A, "members_per_launch": members_per_launch,
-                "algorithmic_bytes_per_launch": A * members_per_launch,
-                "avg_launch_us": k_avg * 1e6, "min_launch_us": float(samples.min()) * 1e6,
-                "launches_timed": int(samples.size) * per_batch * n_launch,
-                "stream_copy_GBs": copy_gbs, "stream_copy_16B_per_lane_GBs": copy_wide_gbs,
-                "frac_of_stream_copy": achieved / max(copy_gbs, copy_wide_gbs)}
 
-    # ---- end-of-run exchange (the only collective): summary statistics of T over all members ------
-    summary, summary_error = None, None
-    if eng.T is not None:
-        torch.cuda.synchronize(dev)
-        ts = time.perf_counter()
-        done = min(a.warmup + a.steps, n_scen)                  # scenario steps the timed run has written
-        years = [t for t in (249, 499, 749) if t < done] or [done - 1]
-        try:
-            summary = gather_summary(eng.T[years], percentiles=(5.0, 50.0, 95.0))
-        except Exception as exc:  # noqa: BLE001 - the exchange is outside the timed region: report, do not lose the line
-            summary = None
-            summary_error = f"{type(exc).__name__}: {exc}"
-        torch.cuda.synchronize(dev)
-        summary_ms = (time.perf_counter() - ts) * 1e3
+    def copy_rate(fn_name):
+        f = getattr(eng.lib, fn_name)
+        call = lambda: f(n_copy, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), eng._stream())  # noqa: E731
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            call()
+        e1.record()
+        e1.synchronize()
+        return 2 * n_copy * 8 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    copy_gbs = copy_rate("fiveeq_stream_copy_f64")
+    copy_wide_gbs = copy_rate("fiveeq_stream_copy_wide_f64")
+    del src, dst
+    roofline["stream_copy_GBs"] = copy_gbs
+    roofline["stream_copy_16B_per_lane_GBs"] = copy_wide_gbs
+    if not fusedlike:
+        roofline["frac_of_stream_copy"] = roofline["achieved"] / max(copy_gbs, copy_wide_gbs)
+
+    # ---- the per-step kernel with NOTHING cache-resident: an ensemble whose state + parameters are several times the
+    # Infinity Cache, one launch per step over all of it (chunk-major schedule off), trajectories stored -------------
+    if not fusedlike and world == 1 and not a.no_hbm_resident and a.hbm_resident_members > 0:
+        n_big, n_s = a.hbm_resident_members, 112
+        reps = -(-n_big // n_local)
+        pb = dict(p)
+        for key in ("r0", "rC", "rT", "q"):
+            pb[key] = p[key].repeat(1, reps)[:, :n_big].contiguous()
+        big = EnsembleEngine(pb, n_big, emissions.rcp_like_emissions(n_scen, G)[250:250 + n_s], dtype=dtype, device=dev,
+                             store_trajectory=not a.no_trajectory, chunk_members=0)
+        w = 8 if a.dtype == "f64" else 4
+        resident = w * (eng.sum_pools + 2 + 3 * G + 2) * n_big
+        big.run(0, 6)
+        sm = event_timed(big, lambda t0_, t1_: big.run(t0_, t1_), 0, n_s, 100, 1) / 100
+        Ab = big.bytes_per_member_step("per_step")
+        ach = Ab * n_big / float(sm.mean()) / 1e9
+        roofline["hbm_resident"] = {"members": n_big, "state_and_parameter_bytes": resident,
+                                    "x_infinity_cache": resident / (256 << 20), "avg_launch_us": float(sm.mean()) * 1e6,
+                                    "achieved": ach, "frac": ach / HBM_PEAK_GBS, "chunk_major": False,
+                                    "algorithmic_bytes_per_launch": Ab * n_big}
+        roofline["hbm_resident_frac"] = ach / HBM_PEAK_GBS
+        big.close()
+        del big, pb
 
     out = {
         "metric": "ensemble_member_timesteps_per_sec", "value": value, "unit": "member-timesteps/s",
@@ -306,22 +420,32 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{a.workload}: {desc}", "members_per_gpu": per_gpu, "members_total": n_total,
                    "gases": G, "pools": eng.pools, "scenario_steps": n_scen, "mode": a.mode,
+                   "steps_per_launch": (roofline.get("steps_per_launch", 1)),
                    "trajectory_stored": eng.C is not None, "parallelism": f"member-shard x{world}",
                    "chunk_members": eng.chunk_members,
                    "collective_backend": "rccl" if backend == "nccl" else backend,
-                   "emissions_sha256": emissions.emissions_sha256(E)[:16], "lhs_seed": params.LHS_SEED},
+                   "emissions_sha256": emissions.emissions_sha256(E)[:16], "lhs_seed": params.LHS_SEED,
+                   "lhs_design": "shard-computable (keyed Feistel bijection), drawn on the device",
+                   "setup_s_rank0": setup_s},
         "roofline": roofline,
     }
     if summary is not None and rank == 0:
-        out["summary"] = {"years": years, "gather_ms": summary_ms,
+        out["summary"] = {"years": years, "gather_ms": summary_ms, "gather_ms_is": "second (warm) call",
+                          "bytes_to_root": summary_stats.get("bytes_to_root"),
+                          "allreduce_bytes": summary_stats.get("allreduce_bytes"),
                           "T_mean": [float(x) for x in summary["mean"]],
                           "T_p05_p50_p95": [[float(v) for v in row] for row in summary["percentiles"]]}
-    if summary_error is not None and rank == 0:
+    if summary_error is not None:
         out["summary"] = {"error": summary_error}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kind, G, a.cpu_sample_members, n_scen)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if summary_error is not None:
+        # a rank that failed inside the exchange must not walk into another collective: the peers may be stuck in
+        # the one it left.  Exit non-zero; the launcher tears the job down.
+        print(f"rank {rank}: summary exchange failed: {summary_error}", file=sys.stderr, flush=True)
+        os._exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -33,7 +33,7 @@ LAUNCH_BOUNDARY_S = 2.0e-6           # dependent-launch boundary on one stream (
 
 
 def _rows(x, K, N, name):
-    if isinstance(x, torch.Tensor):                    # already on a device (params.sample_ensemble_device)
+    if isinstance(x, torch.Tensor):                    # already on a device (params.sample_ensemble_shard)
         if tuple(x.shape) != (K, N):
             raise ValueError(f"{name}: tensor shape {tuple(x.shape)}, want [{K},{N}]")
         return x
@@ -54,7 +54,7 @@ class EnsembleEngine:
 
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
                  device=None, store_trajectory=True, output_steps=None, store_concentrations=True,
-                 collect_stats=False, hist=None, hist_ring_steps=32,
+                 collect_stats=False, hist=None, hist_ring_steps="auto",
                  concentration_driven=False, chunk_members="auto", R0=None, S0=None, lib_path=None):
         """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
         stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
@@ -67,7 +67,7 @@ class EnsembleEngine:
         kernel's time loop (LDS-privatised, no scratch memory); run(mode="per_step") histograms each step's T row
         right behind the step kernel (one scratch row, still in the Infinity Cache); run(mode="fused") streams it — the fused kernel
         parks T of `hist_ring_steps` steps at a time in a two-slot ring ([2, S, N], 0.8 GB for 12.5M fp32 members
-        at S = 16; default S = 32) and the histogram kernel drains one slot on a second HIP stream while the next is computed.
+        at S = 16; default: what 8 GB hold, at most 128 steps) and the histogram kernel drains one slot on a second HIP stream while the next is computed.
         concentration_driven: inverse mode — `emissions` holds the TARGET concentrations [n_steps, G]
         at the end of each step (shared by all members); the per-member emissions that reach them
         are diagnosed into `self.E` ([n_rows, G, N], aliasing `self.C`), and `self.cumE` [G, N] is
@@ -146,6 +146,9 @@ class EnsembleEngine:
                     raise ValueError("in-loop histograms are not available in concentration-driven mode")
                 self.hist_spec = (lo_h, hi_h, nb)
                 self.T_hist = torch.zeros((self.n_steps, nb), dtype=torch.int64, device=dev)
+            if hist_ring_steps == "auto":      # as long as 8 GB of ring allow, at most 128 steps: every chunk boundary
+                w_ = 8 if dtype == torch.float64 else 4       # costs one state + parameter round trip through HBM
+                hist_ring_steps = min(128, max(8, (8 << 30) // (2 * N * w_)))
             self.hist_ring_steps = max(1, min(int(hist_ring_steps), self.n_steps))
             self._ring = None            # allocated by the first streamed-histogram run
         if chunk_members == "auto":

@@ -13,16 +13,14 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """The built libraries are git-ignored: a fresh checkout has none.  Build them once (hipcc
-    cross-compiles gfx950 without a GPU; gcc for the oracle) so that the suite does not depend on
-    someone having called __graft_entry__.build() first."""
+    """The built libraries are git-ignored: a fresh checkout has none, and a checkout with edited sources has stale
+    ones.  `make` is incremental (a no-op when up to date), so run it every session: hipcc cross-compiles gfx950
+    without a GPU; gcc builds the oracle.  Then check that the loaded library is the ABI the binding expects."""
     import subprocess
-    hip_lib = os.path.join(ROOT, "fiveeqscm_amd", "csrc", "libfiveeq_hip.so")
-    if not os.path.exists(hip_lib):
-        subprocess.run(["make", "-C", os.path.dirname(hip_lib)], check=True)
-    ora_lib = os.path.join(ROOT, "oracle", "libfiveeq_oracle.so")
-    if not os.path.exists(ora_lib):
-        subprocess.run(["make", "-C", os.path.dirname(ora_lib)], check=True)
+    for sub in (("fiveeqscm_amd", "csrc"), ("oracle",)):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, *sub)], check=True)
+    from fiveeqscm_amd import _capi
+    assert _capi.load().fiveeq_abi_version() == _capi.ABI_VERSION
 
 
 @pytest.fixture(scope="session")

@@ -21,7 +21,12 @@ import sys
 
 import numpy as np
 
-from U_FaIR.concentrations import calculate_hfc_conc  # the reference, unmodified
+import U_FaIR.concentrations as _ref_module  # the reference, unmodified
+from U_FaIR.concentrations import calculate_hfc_conc
+
+# this repo ships a `U_FaIR/concentrations.py` of its own (a re-export of the drop-in): make sure the vectors
+# below really come from the reference's file, never from that shim
+assert os.path.realpath(_ref_module.__file__).startswith("/root/reference/"), _ref_module.__file__
 
 
 def hexlist(x):

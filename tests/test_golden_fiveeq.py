@@ -1,0 +1,158 @@
+"""The five-equation golden fixtures (tests/golden/fiveeq_golden.json, generated FROM THE BUILD'S OWN ORACLE, and
+tests/golden/fiveeq_mp_reference.json, a 50-digit mpmath evaluation of the same recurrence).
+
+They do not pin parity with the reference — it has no implementation of this path.  They pin
+the oracle: (1) both oracles must keep reproducing the committed trajectories (a silent joint change of oracle and
+kernels can no longer pass); (2) the fp64 oracle's accumulated rounding over 750 steps is bounded against 50-digit
+arithmetic, which is what gives the kernels' "<= 1e-10 from the oracle" a meaning in absolute terms.
+The GPU leg (kernels against the same fixture at 1e-10) is at the bottom, marked gpu.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+import fiveeq_cases as cases  # noqa: E402
+from oracle import c_oracle, fiveeq_oracle as npo  # noqa: E402
+
+
+def _load(name):
+    with open(os.path.join(HERE, "golden", name)) as fh:
+        return json.load(fh)
+
+
+def _arr(hexes, shape):
+    return np.array([float.fromhex(h) for h in hexes]).reshape(shape)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return _load("fiveeq_golden.json")
+
+
+@pytest.mark.parametrize("kind", ["co2", "multigas"])
+def test_golden_member_set_is_the_committed_one(golden, kind):
+    """The fixture's inputs are reproducible from code: the shard-computable LHS + the corner table."""
+    p, N = cases.members(kind)
+    rec = golden["cases"][kind]
+    G = 1 if kind == "co2" else 3
+    assert rec["n_members"] == N == 24 and golden["steps"] == cases.STEPS
+    for name, rows in (("r0", G), ("rC", G), ("rT", G), ("q", 2)):
+        assert np.array_equal(_arr(rec[name], (rows, N)), p[name]), name
+
+
+@pytest.mark.parametrize("kind", ["co2", "multigas"])
+def test_numpy_oracle_reproduces_its_golden_trajectories(golden, kind):
+    p, N = cases.members(kind)
+    rec = golden["cases"][kind]
+    G = 1 if kind == "co2" else 3
+    out = npo.run(cases.scenario(kind), p, N, keep=("C", "T", "alpha"))
+    S = len(cases.STEPS)
+    # same NumPy build: bit for bit; another NumPy / libm may move an ulp per transcendental: 1e-13 is the contract
+    for name, shape in (("C", (S, G, N)), ("T", (S, N)), ("alpha", (S, G, N))):
+        np.testing.assert_allclose(out[name][cases.STEPS], _arr(rec[name], shape), rtol=1e-13, atol=1e-15, err_msg=name)
+    np.testing.assert_allclose(np.concatenate(out["R"], axis=0), _arr(rec["R_final"], (-1, N)), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(out["S"], _arr(rec["S_final"], (2, N)), rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("kind", ["co2", "multigas"])
+def test_c_oracle_reproduces_the_golden_trajectories(golden, kind):
+    p, N = cases.members(kind)
+    rec = golden["cases"][kind]
+    G = 1 if kind == "co2" else 3
+    out = c_oracle.run(cases.scenario(kind), p, N)
+    S = len(cases.STEPS)
+    np.testing.assert_allclose(out["C"][cases.STEPS], _arr(rec["C"], (S, G, N)), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(out["T"][cases.STEPS], _arr(rec["T"], (S, N)), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(out["R"], _arr(rec["R_final"], (-1, N)), rtol=1e-13, atol=1e-15)
+
+
+def test_inverse_mode_golden(golden):
+    p, N = cases.members("co2")
+    E = cases.scenario("co2")
+    rec = golden["cases"]["co2_inverse"]
+    conc = npo.run(E, p, N, keep=("C",))["C"][:, :, rec["target_member"]]
+    inv = npo.run_inverse(conc, p, N)
+    S = len(cases.STEPS)
+    np.testing.assert_allclose(inv["E"][cases.STEPS], _arr(rec["E"], (S, 1, N)), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(inv["T"][cases.STEPS], _arr(rec["T"], (S, N)), rtol=1e-13, atol=1e-15)
+    # member 0 driven by its own concentration pathway recovers the emissions it was run with
+    np.testing.assert_allclose(inv["E"][:, 0, 0], E[:, 0], rtol=1e-8, atol=1e-9)
+
+
+# the bound asserted below; the measured worst case is printed by the test and recorded in DESIGN.md section 5
+MP_RTOL = 1e-13
+
+
+@pytest.mark.parametrize("kind", ["co2", "multigas"])
+def test_fp64_oracle_against_50_digit_arithmetic(kind, capsys):
+    """|oracle - mp| <= 1e-13 |mp| + 1e-15 on C and T over the whole 750-step run for the selected members
+    (two LHS members and four corners of the box, incl. all-high: highest sensitivity, strongest feedback)."""
+    ref = _load("fiveeq_mp_reference.json")
+    assert ref["steps"] == cases.STEPS and ref["digits"] >= 50
+    p, N = cases.members(kind)
+    E = cases.scenario(kind)
+    worst = {}
+    for label, runner in (("numpy", lambda: npo.run(E, p, N)), ("c", lambda: c_oracle.run(E, p, N))):
+        out = runner()
+        for i, m in enumerate(ref["members"]):
+            C_mp = np.array([[float(v) for v in row] for row in ref["cases"][kind]["C"][i]])      # [S, G]
+            T_mp = np.array([float(v) for v in ref["cases"][kind]["T"][i]])
+            eC = np.abs(out["C"][cases.STEPS][:, :, m] - C_mp) / (np.abs(C_mp) + 1e-300)
+            eT = np.abs(out["T"][cases.STEPS][:, m] - T_mp) / (np.abs(T_mp) + 1e-2)               # T starts at 0
+            worst[label] = max(worst.get(label, 0.0), float(eC.max()), float(eT.max()))
+            assert np.all(np.abs(out["C"][cases.STEPS][:, :, m] - C_mp) <= MP_RTOL * np.abs(C_mp) + 1e-15)
+            assert np.all(np.abs(out["T"][cases.STEPS][:, m] - T_mp) <= MP_RTOL * np.abs(T_mp) + 1e-15)
+    with capsys.disabled():
+        print(f"\n  [{kind}] worst relative distance of the fp64 oracles from 50-digit arithmetic: "
+              f"numpy {worst['numpy']:.2e}, C {worst['c']:.2e}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["co2", "multigas"])
+@pytest.mark.parametrize("mode", ["per_step", "fused", "tiled"])
+def test_kernels_reproduce_the_golden_trajectories(golden, kind, mode):
+    """The HIP kernels, through the C ABI, against the committed oracle trajectories: <= 1e-10 relative on C and T
+    (BASELINE.json north_star), and against the 50-digit reference at the same tolerance."""
+    torch = pytest.importorskip("torch")
+    from fiveeqscm_amd.engine import EnsembleEngine
+    p, N = cases.members(kind)
+    rec = golden["cases"][kind]
+    G = 1 if kind == "co2" else 3
+    eng = EnsembleEngine(p, N, cases.scenario(kind), device="cuda:0", output_steps=cases.STEPS)
+    eng.run(mode=mode)
+    torch.cuda.synchronize()
+    S = len(cases.STEPS)
+    C, T = eng.C.cpu().numpy(), eng.T.cpu().numpy()
+    wantC, wantT = _arr(rec["C"], (S, G, N)), _arr(rec["T"], (S, N))
+    assert np.all(np.abs(C - wantC) <= 1e-10 * np.abs(wantC) + 1e-13)
+    assert np.all(np.abs(T - wantT) <= 1e-10 * np.abs(wantT) + 1e-13)
+    np.testing.assert_allclose(eng.R.cpu().numpy(), _arr(rec["R_final"], (-1, N)), rtol=1e-10, atol=1e-12)
+    ref = _load("fiveeq_mp_reference.json")
+    for i, m in enumerate(ref["members"]):
+        C_mp = np.array([[float(v) for v in row] for row in ref["cases"][kind]["C"][i]])
+        T_mp = np.array([float(v) for v in ref["cases"][kind]["T"][i]])
+        assert np.all(np.abs(C[:, :, m] - C_mp) <= 1e-10 * np.abs(C_mp) + 1e-13)
+        assert np.all(np.abs(T[:, m] - T_mp) <= 1e-10 * np.abs(T_mp) + 1e-13)
+
+
+@pytest.mark.gpu
+def test_inverse_kernel_reproduces_the_golden_emissions(golden):
+    torch = pytest.importorskip("torch")
+    from fiveeqscm_amd.engine import EnsembleEngine
+    p, N = cases.members("co2")
+    E = cases.scenario("co2")
+    rec = golden["cases"]["co2_inverse"]
+    conc = npo.run(E, p, N, keep=("C",))["C"][:, :, rec["target_member"]]
+    eng = EnsembleEngine(p, N, conc, device="cuda:0", output_steps=cases.STEPS, concentration_driven=True)
+    eng.run()
+    torch.cuda.synchronize()
+    S = len(cases.STEPS)
+    np.testing.assert_allclose(eng.E.cpu().numpy(), _arr(rec["E"], (S, 1, N)), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(eng.T.cpu().numpy(), _arr(rec["T"], (S, N)), rtol=1e-10, atol=1e-13)

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 --pmc SQ_* passes to per-kernel means and to VALU wave-instructions per wave-step.
+
+    python tools/pmc_valu.py <summary.csv> <valu.json> <steps_per_fused_launch> <members> <tile_k_steps> <pass_dir> [...]
+
+(the tiled kernel is persistent: its SQ_WAVES are workgroup waves, not member waves, so its per-wave-step figure is
+total VALU / (ceil(members / 64) x tile_k_steps))
+
+summary.csv  : kernel, counter, dispatches, mean value per dispatch   (committed under profiles/<round>/)
+valu.json    : {"step:f64:4,1,1": {"valu_per_wave_step": ..., ...}, "fused:f64:4,1,1": {...}, ...}  (bench.py reads it)
+
+Units (MI355X_MICROARCH.md): SQ_INSTS_* count wave-instructions; SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES count
+quad-cycles summed over waves; SQ_BUSY_CYCLES is summed over shader engines.  One wave64 VALU instruction occupies its
+SIMD for >= 4 cycles, so  issue fraction = SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel time x 2.4 GHz).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def main():
+    out_csv, out_json, fused_steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    members, tile_k = int(sys.argv[4]), int(sys.argv[5])
+    acc = collections.defaultdict(list)
+    dur = collections.defaultdict(list)
+    for d in sys.argv[6:]:
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as fh:
+                for row in csv.DictReader(fh):
+                    name = row["Kernel_Name"]
+                    if "fiveeq::" not in name:
+                        continue
+                    k = name.split("(")[0].replace("void ", "").strip()
+                    acc[(k, row["Counter_Name"])].append(float(row["Counter_Value"]))
+                    dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
+    with open(out_csv, "w") as fh:
+        fh.write("kernel,counter,dispatches,mean_per_dispatch\n")
+        for (k, c), v in sorted(acc.items()):
+            fh.write(f"\"{k}\",{c},{len(v)},{sum(v) / len(v):.6g}\n")
+        for k, v in sorted(dur.items()):
+            fh.write(f"\"{k}\",DURATION_US_UNDER_PMC,{len(v)},{sum(v) / len(v):.6g}\n")
+    doc = {}
+    if os.path.exists(out_json):
+        with open(out_json) as fh:
+            doc = json.load(fh)
+    kernels = {k for k, _ in acc}
+    for k in sorted(kernels):
+        m = re.match(r"fiveeq::(step|fused|tile)_kernel<(double|float), (\d), (\d), (\d)(?:, (true|false))?>", k)
+        if not m or m.group(6) == "true":
+            continue
+        mean = lambda c: (sum(acc[(k, c)]) / len(acc[(k, c)])) if (k, c) in acc else None   # noqa: E731
+        valu, waves = mean("SQ_INSTS_VALU"), mean("SQ_WAVES")
+        if not valu or not waves:
+            continue
+        steps = 1 if m.group(1) == "step" else fused_steps
+        if m.group(1) == "tile":
+            steps, waves = tile_k, float(-(-members // 64))
+        key = f"{m.group(1)}:{'f64' if m.group(2) == 'double' else 'f32'}:{m.group(3)},{m.group(4)},{m.group(5)}"
+        rec = {"kernel": k, "valu_per_wave_step": valu / waves / steps, "waves": waves, "steps_per_launch": steps,
+               "dispatches": len(acc[(k, "SQ_INSTS_VALU")])}
+        for c, nm in (("SQ_INSTS_SALU", "salu_per_wave_step"), ("SQ_INSTS_LDS", "lds_per_wave_step"),
+                      ("SQ_INSTS_VMEM_RD", "vmem_rd_per_wave_step"), ("SQ_INSTS_VMEM_WR", "vmem_wr_per_wave_step")):
+            if mean(c) is not None:
+                rec[nm] = mean(c) / waves / steps
+        wc = mean("SQ_WAVE_CYCLES")
+        if wc:
+            for c, nm in (("SQ_ACTIVE_INST_VALU", "valu_active_frac_of_wave_cycles"), ("SQ_WAIT_ANY", "wait_any_frac"),
+                          ("SQ_WAIT_INST_ANY", "wait_inst_any_frac"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_frac")):
+                if mean(c) is not None:
+                    rec[nm] = mean(c) / wc
+        doc[key] = rec
+    with open(out_json, "w") as fh:
+        json.dump(doc, fh, indent=1, sort_keys=True)
+    print(json.dumps(doc, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

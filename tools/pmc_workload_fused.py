@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Workload for rocprofv3 --pmc passes on the time-fused kernel: one 300-step launch."""
+"""Workload for the rocprofv3 --pmc SQ_* passes of the time-fused family: fused and tiled launches of STEPS steps
+each (the reducer divides per-wave counts by STEPS).
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ... -- python3 tools/pmc_workload_fused.py [members] [f64|f32] [steps] [tile_k] [kind]"""
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,13 +13,22 @@ from fiveeqscm_amd import emissions, params  # noqa: E402
 from fiveeqscm_amd.engine import EnsembleEngine  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-dtype = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "f32") else torch.float64
-base = params.sample_ensemble(params.default_params("multigas"), 65536)
-p = dict(base)
-for k in ("r0", "rC", "rT", "q"):
-    p[k] = np.tile(base[k], (1, -(-N // 65536)))[:, :N]
-eng = EnsembleEngine(p, N, emissions.rcp_like_emissions(330, 3), device="cuda:0", dtype=dtype)
-eng.run(0, 20, mode="fused")
-eng.run(20, 320, mode="fused")
+dt = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "f32") else torch.float64
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 96
+kind = sys.argv[5] if len(sys.argv) > 5 else "multigas"
+p = params.sample_ensemble_shard(params.default_params(kind), N, device="cuda:0", dtype=dt)
+E = emissions.rcp_like_emissions(750, 3 if kind == "multigas" else 1)[250:250 + STEPS]
+eng = EnsembleEngine(p, N, E, dtype=dt, device="cuda:0", store_trajectory=False, collect_stats=True,
+                     hist=(-2.0, 12.0, 4096))
+for _ in range(2):
+    eng.reset_state()
+    fn = getattr(eng.lib, f"fiveeq_run_fused_{eng._sfx}")          # the plain fused kernel (no histogram pipeline)
+    assert fn(*eng._run_args(0, STEPS), eng._stream()) == 0
+    torch.cuda.synchronize()
+# the tiled kernel as ONE launch of min(STEPS, tile_steps) is not comparable; run it with k_steps dividing STEPS
+k = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+assert STEPS % k == 0 and k <= eng.tile_steps()
+eng.reset_state()
+eng.run(mode="tiled", k_steps=k)
 torch.cuda.synchronize()
-print("done")
+print("pmc fused workload done", N, dt, STEPS, "tile k_steps", k)

@@ -35,20 +35,19 @@ def main():
     G = 3 if a.kind == "multigas" else 1
     libs = [x for x in a.libs.split(",") if x] or [None]
     E = emissions.rcp_like_emissions(a.scenario_steps, G)
-    base = params.sample_ensemble(params.default_params(a.kind), 65536)
     print(f"{'lib':28s} {'dtype':5s} {'members':>9s} {'mode':9s} {'us/step(med)':>12s} {'us/step(min)':>12s} "
           f"{'Gmember-steps/s':>15s} {'alg GB/s':>9s}")
     for N in [int(x) for x in a.members.split(",")]:
-        p = dict(base)
-        reps = -(-N // 65536)
-        for k in ("r0", "rC", "rT", "q"):
-            p[k] = np.tile(base[k], (1, reps))[:, :N]
+        p = params.sample_ensemble_shard(params.default_params(a.kind), N, device="cuda:0")   # drawn on the device
         for dt in a.dtypes.split(","):
             dtype = torch.float64 if dt == "f64" else torch.float32
             # ONE set of device buffers; the builds under test are swapped in as `eng.lib`.  (Separate
             # engines per build showed up to 4.5 % spread between IDENTICAL libraries, purely from where
             # their 24 GB of buffers landed.)
-            eng = EnsembleEngine(p, N, E, dtype=dtype, device="cuda:0", lib_path=libs[0],
+            pd = dict(p)
+            for k in ("r0", "rC", "rT", "q"):
+                pd[k] = p[k].to(dtype)
+            eng = EnsembleEngine(pd, N, E, dtype=dtype, device="cuda:0", lib_path=libs[0],
                                  store_trajectory=not a.no_trajectory, collect_stats=a.stats)
             from fiveeqscm_amd import _capi
             handles = {lib: _capi.load(lib) for lib in libs}

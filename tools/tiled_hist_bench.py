@@ -65,7 +65,7 @@ def main():
             print(f"  tiled K={kk:2d} hist {nb:4d} bins        {t / a.steps * 1e6:9.2f} us/step  {t / t_fused - 1:+.1%} vs fused"
                   f"   A_tile = {eng.bytes_per_member_step('tiled', kk):.1f} B/member-step")
         assert eng.T_hist.sum(1).min().item() == N
-        for S in (8, 16, 32):
+        for S in (16, 32, 64, 128):
             eng.hist_ring_steps, eng._ring = S, None
             t = timed(eng, a.reps, mode="fused")
             print(f"  fused + streamed hist {nb:4d} bins, ring 2x{S:2d} steps {t / a.steps * 1e6:9.2f} us/step  "
