@@ -96,6 +96,9 @@ SIGNATURES = {
     "fiveeq_hfc_conc_f64": (ctypes.c_int, [_i64, _i64, _i32, _p, _p, _p, _p]),
     "fiveeq_hist_rows_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
     "fiveeq_hist_rows_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
+    "fiveeq_hist_rows_stats_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p, _p]),
+    "fiveeq_hist_rows_stats_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p, _p]),
+    "fiveeq_hist_rows_chunks": (ctypes.c_int64, [_i32, _i64]),
     "fiveeq_stream_copy_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
     "fiveeq_stream_copy_wide_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
     "fiveeq_math_probe_f64": (ctypes.c_int, [_i32, _i64, _p, _p, _p]),

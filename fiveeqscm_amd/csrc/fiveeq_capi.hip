@@ -606,9 +606,17 @@ int fiveeq_stream_copy_f64(int64_t n, const double* src, double* dst, void* stre
 }  // extern "C"
 
 namespace {
+// members per workgroup of the histogram pass: as coarse as still gives ~2048 workgroups over all rows
+// (fewer, fuller flushes of the LDS histogram), a multiple of the block size
+int64_t hist_chunk(int32_t n_rows, int64_t n) {
+    int64_t chunk = (n * (n_rows > 0 ? n_rows : 1) + 2047) / 2048;
+    if (chunk < fiveeq::HIST_CHUNK_MIN) chunk = fiveeq::HIST_CHUNK_MIN;
+    return (chunk + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK * FIVEEQ_BLOCK;
+}
+
 template <typename T>
 int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, double hi, int32_t n_bins,
-              uint64_t* hist, void* stream) {
+              uint64_t* hist, double* moments, void* stream) {
     if (n_rows < 0) return fail(FIVEEQ_E_INVALID, "n_rows=%d must be >= 0", n_rows);
     if (n < 1 || ld < n) return fail(FIVEEQ_E_INVALID, "n_members=%lld, ld=%lld invalid", (long long)n, (long long)ld);
     if (n_bins < 1 || n_bins > fiveeq::HIST_MAX_BINS)
@@ -617,15 +625,12 @@ int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, d
     if (n_rows == 0) return FIVEEQ_OK;
     if (!rows || !hist) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
     if (n_rows > 65535) return fail(FIVEEQ_E_INVALID, "n_rows=%d exceeds the 65535 rows of one launch", n_rows);
-    // members per workgroup: as coarse as still gives ~2048 workgroups over all rows (fewer, fuller flushes)
-    int64_t chunk = (n * n_rows + 2047) / 2048;
-    if (chunk < fiveeq::HIST_CHUNK_MIN) chunk = fiveeq::HIST_CHUNK_MIN;
-    chunk = (chunk + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK * FIVEEQ_BLOCK;
+    const int64_t chunk = hist_chunk(n_rows, n);
     const int64_t chunks = (n + chunk - 1) / chunk;
     if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
     hipLaunchKernelGGL(fiveeq::hist_rows_kernel<T>, dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
                        (hipStream_t)stream, n, ld, chunk, rows, lo, (double)n_bins / (hi - lo), n_bins,
-                       reinterpret_cast<unsigned long long*>(hist));
+                       reinterpret_cast<unsigned long long*>(hist), moments);
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;
 }
@@ -647,11 +652,26 @@ int math_probe(int32_t op, int64_t n, const T* x, T* y, void* stream) {
 extern "C" {
 int fiveeq_hist_rows_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, double lo, double hi,
                          int32_t n_bins, uint64_t* hist, void* stream) {
-    return hist_rows<double>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, stream);
+    return hist_rows<double>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, nullptr, stream);
+}
+int fiveeq_hist_rows_stats_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, double lo, double hi,
+                               int32_t n_bins, uint64_t* hist, double* moments, void* stream) {
+    if (!moments) return fail(FIVEEQ_E_INVALID, "moments is NULL");
+    return hist_rows<double>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, moments, stream);
+}
+int fiveeq_hist_rows_stats_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, double lo, double hi,
+                               int32_t n_bins, uint64_t* hist, double* moments, void* stream) {
+    if (!moments) return fail(FIVEEQ_E_INVALID, "moments is NULL");
+    return hist_rows<float>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, moments, stream);
+}
+int64_t fiveeq_hist_rows_chunks(int32_t n_rows, int64_t n_members) {
+    if (n_rows < 1 || n_members < 1) return 0;
+    const int64_t chunk = hist_chunk(n_rows, n_members);
+    return (n_members + chunk - 1) / chunk;
 }
 int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, double lo, double hi,
                          int32_t n_bins, uint64_t* hist, void* stream) {
-    return hist_rows<float>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, stream);
+    return hist_rows<float>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, nullptr, stream);
 }
 int fiveeq_math_probe_f64(int32_t op, int64_t n, const double* x, double* y, void* stream) {
     return math_probe<double>(op, n, x, y, stream);

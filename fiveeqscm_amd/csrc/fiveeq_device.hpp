@@ -836,14 +836,18 @@ template <typename T>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n, const int64_t ld, const int64_t chunk,
                                                                  const T* __restrict__ rows, const double lo,
                                                                  const double inv_w, const int n_bins,
-                                                                 unsigned long long* __restrict__ hist) {
+                                                                 unsigned long long* __restrict__ hist,
+                                                                 double* __restrict__ moments /* [rows][chunks][4] or nullptr */) {
     __shared__ unsigned int h[HIST_MAX_BINS];
+    __shared__ double red[FIVEEQ_BLOCK / 64][4];
     for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) h[b] = 0u;
     __syncthreads();
     const int64_t row = blockIdx.y;
     const int64_t m0 = (int64_t)blockIdx.x * chunk;
     const int64_t m1 = min(m0 + chunk, n);
     const T* x = rows + row * ld;
+    const double inf = __builtin_inf();
+    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;      // this pass reads every value anyway: the moments ride along
     auto count = [&](const T xv) {
         const double v = (double)xv;
         if (v == v) {
@@ -851,6 +855,10 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
             const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
             atomicAdd(&h[b], 1u);
         }
+        s1 += v;
+        s2 = __builtin_fma(v, v, s2);
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
     };
     int64_t m = m0 + threadIdx.x;
     for (; m + 3 * FIVEEQ_BLOCK < m1; m += 4 * FIVEEQ_BLOCK) {      // four independent loads in flight per lane
@@ -861,7 +869,32 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
         count(v3);
     }
     for (; m < m1; m += FIVEEQ_BLOCK) count(x[m]);
+    if (moments != nullptr) {
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            s1 += __shfl_xor(s1, sh);
+            s2 += __shfl_xor(s2, sh);
+            mn = fmin(mn, __shfl_xor(mn, sh));
+            mx = fmax(mx, __shfl_xor(mx, sh));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            double* r = red[threadIdx.x >> 6];
+            r[0] = s1, r[1] = s2, r[2] = mn, r[3] = mx;
+        }
+    }
     __syncthreads();
+    if (moments != nullptr && threadIdx.x == 0) {
+        double a = red[0][0], b = red[0][1], c = red[0][2], d = red[0][3];
+#pragma unroll
+        for (int w = 1; w < FIVEEQ_BLOCK / 64; ++w) {
+            a += red[w][0];
+            b += red[w][1];
+            c = fmin(c, red[w][2]);
+            d = fmax(d, red[w][3]);
+        }
+        double* o = moments + (row * gridDim.x + blockIdx.x) * 4;
+        o[0] = a, o[1] = b, o[2] = c, o[3] = d;
+    }
     unsigned long long* out = hist + row * n_bins;
     for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) {
         const unsigned int c = h[b];

@@ -136,6 +136,9 @@ class EnsembleEngine:
             self.n_waves = int(self.lib.fiveeq_stats_waves(N))
             self.T_stats = (torch.zeros((self.n_waves, self.n_steps, 4), dtype=torch.float64, device=dev)
                             if collect_stats else None)
+            # per-step (count, sum, sum^2, min, max) produced by the streamed histogram pass instead of the kernels
+            self._step_sums = (torch.zeros((self.n_steps, 5), dtype=torch.float64, device=dev) if collect_stats else None)
+            self._step_sums_valid = np.zeros(self.n_steps, dtype=bool)
             self.hist_spec = None
             self.T_hist = None
             if hist is not None:
@@ -205,10 +208,11 @@ class EnsembleEngine:
         if self.cumE is not None:
             out["cumE"] = self.cumE.double().cpu().numpy()
         if include_outputs:
-            for name in ("T_stats", "T_hist", "C", "T"):
+            for name in ("T_stats", "T_hist", "C", "T", "_step_sums"):
                 buf = getattr(self, name)
                 if buf is not None:
                     out[name] = buf.cpu().numpy()
+            out["_step_sums_valid"] = self._step_sums_valid.copy()
         return out
 
     def load_state_dict(self, state):
@@ -219,7 +223,9 @@ class EnsembleEngine:
                 raise ValueError(f"{name}: checkpoint shape {src.shape}, engine {tuple(dst.shape)}")
             dst.copy_(torch.from_numpy(src).to(self.dtype))
         self.t_next = int(state.get("t_next", 0))
-        for name in ("T_stats", "T_hist", "C", "T"):
+        if "_step_sums_valid" in state:
+            self._step_sums_valid[:] = np.asarray(state["_step_sums_valid"], dtype=bool)
+        for name in ("T_stats", "T_hist", "C", "T", "_step_sums"):
             dst = getattr(self, name)
             if dst is not None and name in state:
                 src = np.asarray(state[name])
@@ -381,7 +387,8 @@ class EnsembleEngine:
         side = ring["side"]
         side.wait_stream(main)                   # T_hist / self.T may have been touched on the caller's stream
         fused = getattr(self.lib, f"fiveeq_run_fused_{self._sfx}")
-        hist = getattr(self.lib, f"fiveeq_hist_rows_{self._sfx}")
+        with_stats = self._step_sums is not None
+        hist = getattr(self.lib, f"fiveeq_hist_rows_{'stats_' if with_stats else ''}{self._sfx}")
         lo_h, hi_h, nb = self.hist_spec
         stored = {int(t): row for row, t in enumerate(self.out_steps)}
         used = [False, False]
@@ -394,16 +401,29 @@ class EnsembleEngine:
             buf = ring["buf"][slot]
             if used[slot]:
                 main.wait_event(ring["drained"][slot])
+            # no in-kernel statistics here: the histogram pass reads every T anyway and returns the moments with it
             rc = fused(ctypes.byref(self.model), N, N, self._ptr(ring["drive"]), self.n_steps, t, t1, self._ptr(self.r),
                        self._ptr(self.q), self._ptr(self.R), self._ptr(self.S), ctypes.c_void_p(0), self._ptr(buf), S,
-                       self._ptr(self.T_stats), ctypes.c_void_p(main.cuda_stream))
+                       ctypes.c_void_p(0), ctypes.c_void_p(main.cuda_stream))
             side.wait_stream(main)
             if rc == _capi.OK:
-                r0 = t % S
-                rows = buf[r0:r0 + (t1 - t)]
-                rc = hist(t1 - t, N, N, self._ptr(rows), lo_h, hi_h, nb, self._ptr(self.T_hist[t:t1]),
-                          ctypes.c_void_p(side.cuda_stream))
+                r0, k = t % S, t1 - t
+                rows = buf[r0:r0 + k]
                 with torch.cuda.stream(side):
+                    if with_stats:
+                        n_ch = int(self.lib.fiveeq_hist_rows_chunks(k, N))
+                        mom = torch.empty((k, n_ch, 4), dtype=torch.float64, device=dev)
+                        rc = hist(k, N, N, self._ptr(rows), lo_h, hi_h, nb, self._ptr(self.T_hist[t:t1]), self._ptr(mom),
+                                  ctypes.c_void_p(side.cuda_stream))
+                        sums = self._step_sums[t:t1]
+                        sums[:, 0] = float(N)
+                        sums[:, 1:3] = mom[:, :, 0:2].sum(dim=1)
+                        sums[:, 3] = mom[:, :, 2].min(dim=1).values
+                        sums[:, 4] = mom[:, :, 3].max(dim=1).values
+                        self._step_sums_valid[t:t1] = True
+                    else:
+                        rc = hist(k, N, N, self._ptr(rows), lo_h, hi_h, nb, self._ptr(self.T_hist[t:t1]),
+                                  ctypes.c_void_p(side.cuda_stream))
                     for tt in range(t, t1):
                         if tt in stored:
                             self.T[stored[tt]].copy_(buf[tt % S])
@@ -450,16 +470,22 @@ class EnsembleEngine:
 
     # -- on-device summary statistics -----------------------------------------------------
     def stats_sums(self, t_begin=0, t_end=None):
-        """[n, 5] fp64 per step: (count, sum T, sum T^2, min T, max T) over this shard's members,
-        folded over the per-wave records the kernels wrote.  Additive across shards
+        """[n, 5] fp64 per step: (count, sum T, sum T^2, min T, max T) over this shard's members — folded over the
+        per-wave records the kernels wrote, or, for steps that ran through the streamed histogram pipeline
+        (mode='fused' with hist=), as returned by that pass.  Additive across shards
         (fiveeqscm_amd.distributed.reduce_stats)."""
         if self.T_stats is None:
             raise RuntimeError("engine was built with collect_stats=False")
         t_end = self.n_steps if t_end is None else int(t_end)
         s = self.T_stats[:, t_begin:t_end]                      # [W, n, 4]
         cnt = torch.full((s.shape[1],), float(self.n_members), dtype=torch.float64, device=s.device)
-        return torch.stack([cnt, s[:, :, 0].sum(0), s[:, :, 1].sum(0), s[:, :, 2].min(0).values,
-                            s[:, :, 3].max(0).values], dim=1)
+        out = torch.stack([cnt, s[:, :, 0].sum(0), s[:, :, 1].sum(0), s[:, :, 2].min(0).values,
+                           s[:, :, 3].max(0).values], dim=1)
+        valid = self._step_sums_valid[t_begin:t_end]
+        if valid.any():
+            pick = torch.from_numpy(valid).to(out.device)
+            out[pick] = self._step_sums[t_begin:t_end][pick]
+        return out
 
     def stats(self, t_begin=0, t_end=None):
         """dict of per-step ensemble moments of T over this shard: mean, var (population), min, max."""

@@ -240,6 +240,15 @@ int fiveeq_hist_rows_f64(int32_t n_rows, int64_t n_members, int64_t ld, const do
                          double lo, double hi, int32_t n_bins, uint64_t *hist, void *stream);
 int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
                          double lo, double hi, int32_t n_bins, uint64_t *hist, void *stream);
+/* the same pass also returning the MOMENTS of every row — it reads every value anyway:
+ *   moments dev [n_rows][K][4] fp64, K = fiveeq_hist_rows_chunks(n_rows, n_members): per row and member chunk
+ *   (sum, sum of squares, min, max); folding over K gives the row's ensemble moments.  Lets a run that streams its
+ *   T rows through this pass (engine mode "fused" with hist=) drop the in-kernel statistics. */
+int fiveeq_hist_rows_stats_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double *rows,
+                               double lo, double hi, int32_t n_bins, uint64_t *hist, double *moments, void *stream);
+int fiveeq_hist_rows_stats_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
+                               double lo, double hi, int32_t n_bins, uint64_t *hist, double *moments, void *stream);
+int64_t fiveeq_hist_rows_chunks(int32_t n_rows, int64_t n_members);
 
 /* new — shard-computable Latin hypercube: out[k][i] = u_{dim0+k}(m0 + i),
  * 0 <= i < n_members, 0 <= k < n_dim, for a design over n_total members:

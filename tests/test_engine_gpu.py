@@ -560,7 +560,10 @@ def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
     assert torch.allclose(pers.T_stats[..., :2], ref.T_stats[..., :2], rtol=1e-12, atol=0)
     assert torch.equal(eng.T_hist, want)
     assert torch.equal(strm.T_hist, want) and torch.equal(strm.T, ref.T[[3, 50, n_steps - 1]])
-    assert torch.equal(strm.R, ref.R) and torch.equal(strm.T_stats, ref.T_stats)
+    assert torch.equal(strm.R, ref.R)
+    # the streamed pipeline takes its moments from the histogram pass (same numbers, another summation order)
+    a, b = strm.stats_sums(), ref.stats_sums()
+    assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]) and torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-12, atol=0)
     assert torch.equal(bare.T_hist, want) and torch.equal(bare.R, ref.R)
     assert eng.T_hist.sum(1).tolist() == [N] * n_steps
     assert int(want[-1, 0]) + int(want[-1, -1]) > 0 or N < 100           # the edge bins are exercised
