@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 echo "== bench (default workload) =="
 python3 $R/bench.py > $OUT/bench_config3.json 2> $OUT/bench_config3.err || echo "bench failed"
 echo "== bench under rocprofv3 --kernel-trace --stats =="
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-hbm-resident \
     > $OUT/bench_config3_under_rocprof.json 2> $OUT/trace.err || echo "trace failed"
 echo "== PMC passes: HBM traffic (FETCH_SIZE, WRITE_SIZE separately) =="
 for N in 1000000 8000000; do
