@@ -208,20 +208,19 @@ __device__ __forceinline__ float fe_log(float x) {
     return __builtin_fmaf(dk, 6.9313812256e-01f, -((hfsq - tail) - f));                    // k ln2_hi - ...
 }
 
-// sqrt(x) for finite normal x > 0 (a concentration): v_rsq_f64 seed, two Goldschmidt steps and a
-// final residual correction (<= 1 ulp), without the rescaling a full sqrt needs near the ends
-// of the exponent range.
+// sqrt(x) for finite normal x > 0 (a concentration): v_rsq_f64 seed, one Goldschmidt step and a
+// final residual correction (<= 1 ulp; a second Goldschmidt step was redundant), without the rescaling a
+// full sqrt needs near the ends of the exponent range.  (Also tried in round 2 and not kept: magic-number
+// rint + integer-built 2^k in the exp core — 6 fewer VALU per step but +4 VGPRs: 7 -> 6 waves/SIMD in the
+// per-step kernel.)
 __device__ __forceinline__ double fe_sqrt(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
+    const double y = __builtin_amdgcn_rsq(x);                // >= 23 good bits
     double g = x * y;
     double h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
+    const double r = __builtin_fma(-h, g, 0.5);              // one Goldschmidt step: ~2^-45
     g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
-    r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double d = __builtin_fma(-g, g, x);
+    const double d = __builtin_fma(-g, g, x);                // residual (Newton) correction: quadratic again
     return __builtin_fma(d, h, g);
 }
 __device__ __forceinline__ float fe_sqrt(float x) {

@@ -860,6 +860,18 @@ def test_full_size_config5_shard_fp32_sparse_outputs(gpu):
     eng.run(mode="fused")
     torch.cuda.synchronize()
     assert eng.T.shape == (3, N) and eng.C.shape == (3, 3, N)
+    # the same shard with NO concentrations stored and the in-loop histograms of all 750 steps (streamed pipeline):
+    # at the stored years they must equal the histograms of the stored rows, bit for bit, and every step counts N members
+    hst = _engine(p, N, E, dtype=torch.float32, output_steps=years, store_concentrations=False, collect_stats=True,
+                  hist=(-2.0, 12.0, 4096))
+    hst.run(mode="fused")
+    torch.cuda.synchronize()
+    assert torch.equal(hst.T, eng.T)
+    assert torch.equal(hst.T_hist[years], eng.T_histogram(-2.0, 12.0, 4096))
+    assert hst.T_hist.sum(1).tolist() == [N] * n_steps
+    a, b = hst.stats_sums(), eng.stats_sums()
+    assert torch.equal(a[:, 3:], b[:, 3:]) and torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-11, atol=1e-6)
+    del hst
     want = c_oracle.run(E, blk, B, n_threads=8)
     _close(eng.T[:, :B].double(), want["T"][years], rtol=1e-4, atol=1e-5, what="T tile0 fp32")
     _close(eng.C[:, :, :B].double(), want["C"][years], rtol=1e-4, atol=1e-4, what="C tile0 fp32")
