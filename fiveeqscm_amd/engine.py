@@ -63,11 +63,13 @@ class EnsembleEngine:
         collect_stats: also accumulate per-step ensemble moments of T on the device (`stats()`).
         hist=(lo, hi, n_bins): allocate `T_hist` [n_steps, n_bins] (int64), the fixed-bin histogram of T of
         EVERY step, for all-timestep percentiles (distributed.histogram_percentiles) without a stored
-        trajectory.  Two ways to fill it, same counts bit for bit: run(mode="tiled") accumulates it INSIDE the
-        kernel's time loop (LDS-privatised, no scratch memory); run(mode="per_step") histograms each step's T row
-        right behind the step kernel (one scratch row, still in the Infinity Cache); run(mode="fused") streams it — the fused kernel
-        parks T of `hist_ring_steps` steps at a time in a two-slot ring ([2, S, N], 0.8 GB for 12.5M fp32 members
-        at S = 16; default: what 8 GB hold, at most 128 steps) and the histogram kernel drains one slot on a second HIP stream while the next is computed.
+        trajectory.  Three ways to fill it, same counts bit for bit:
+          run(mode="fused")    streams it: the fused kernel parks T of `hist_ring_steps` steps at a time in a two-slot
+                               ring [2, S, N] ("auto": what 8 GB hold, at most 128 steps; 6.4 GB for 12.5M fp32 members
+                               at S = 64) and the histogram kernel drains one slot on a second HIP stream while the next
+                               is computed, returning the per-step moments with it (no in-kernel statistics);
+          run(mode="tiled")    accumulates it INSIDE the kernel's time loop (LDS-privatised, no scratch memory);
+          run(mode="per_step") histograms each step's T row right behind the step kernel (one scratch row).
         concentration_driven: inverse mode — `emissions` holds the TARGET concentrations [n_steps, G]
         at the end of each step (shared by all members); the per-member emissions that reach them
         are diagnosed into `self.E` ([n_rows, G, N], aliasing `self.C`), and `self.cumE` [G, N] is

@@ -259,6 +259,22 @@ def test_fused_and_graph_paths_are_bit_identical_to_per_step(gpu, kind, G, N, n_
         eng.close()
 
 
+def test_fp32_modes_are_bit_identical_too(gpu):
+    """The fp32 twins: every launch shape gives the same bits (the arithmetic is one member_step<float>())."""
+    N, n_steps = 4096 + 37, 70
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(750, 3)[250:250 + n_steps]
+    ref = _engine(p, N, E, dtype=torch.float32)
+    ref.run(mode="per_step")
+    for mode, k in (("fused", None), ("graph", None), ("ksteps", 9), ("tiled", 0), ("tiled", 7)):
+        eng = _engine(p, N, E, dtype=torch.float32)
+        eng.run(mode=mode, k_steps=k)
+        torch.cuda.synchronize()
+        for name in ("C", "T", "R", "S"):
+            assert torch.equal(getattr(eng, name), getattr(ref, name)), (mode, k, name)
+        eng.close()
+
+
 def test_step_by_step_equals_run_and_resume(gpu):
     """Python-driven step(t) == C-driven run(); a run split at any step resumes bit-identically
     (checkpoint = the R,S tensors)."""
