@@ -335,37 +335,51 @@ class EnsembleEngine:
         _capi.check(self.lib, rc)
         self.t_next = t_end
 
+    def _hist_ring(self):
+        """Two-slot ring [2, S, N] of T rows + the drive table whose output row is t mod S (shared by the streamed
+        pipelines of modes 'fused' and 'per_step')."""
+        N, S, dev = self.n_members, self.hist_ring_steps, self.device
+        if self._ring is None:
+            drive = self.drive.clone()
+            drive[:, 7] = torch.arange(self.n_steps, device=dev, dtype=torch.int64).remainder(S).to(self.dtype)
+            self._ring = {"drive": drive, "buf": torch.empty((2, S, N), dtype=self.dtype, device=dev),
+                          "side": torch.cuda.Stream(device=dev), "drained": [torch.cuda.Event(), torch.cuda.Event()]}
+        return self._ring
+
     def _run_per_step_hist(self, t_begin, t_end, stream):
-        """mode='per_step' with hist=: every step launch is followed by a histogram launch over the T row it has just
-        written (a one-row scratch buffer: 8 B per member, read back out of the Infinity Cache), accumulated into
-        T_hist[t].  Chunk-major like the plain per-step path: hist_rows adds each member chunk's counts."""
+        """mode='per_step' with hist=: the per-step kernel (one launch per timestep, enqueued from C, chunk-major like
+        the plain per-step path) stores T of S = hist_ring_steps consecutive steps into a ring strip, then ONE histogram
+        launch over those S rows adds them into T_hist[t:t+S].  Two C calls per S steps and member chunk; the in-kernel
+        per-wave moments stay on (they are free in this kernel)."""
         if self.C is not None:
             raise RuntimeError("per-step histograms carry T only: build the engine with store_concentrations=False "
                                "(or store_trajectory=False), or use mode='tiled'")
-        N = self.n_members
-        if self._ring is None or "row" not in self._ring:
-            drive = self.drive.clone()
-            drive[:, 7] = 0
-            self._ring = dict(self._ring or {}, drive0=drive, row=torch.empty((1, N), dtype=self.dtype, device=self.device))
-        drive0, row = self._ring["drive0"], self._ring["row"]
-        step = getattr(self.lib, f"fiveeq_step_{self._sfx}")
+        N, S = self.n_members, self.hist_ring_steps
+        ring = self._hist_ring()
+        buf = ring["buf"][0]
+        run = getattr(self.lib, f"fiveeq_run_{self._sfx}")
         hist = getattr(self.lib, f"fiveeq_hist_rows_{self._sfx}")
         lo_h, hi_h, nb = self.hist_spec
         stored = {int(t): r for r, t in enumerate(self.out_steps)}
         w = 8 if self.dtype == torch.float64 else 4
         st = self._stream(stream)
+        cur = stream if stream is not None else torch.cuda.current_stream(self.device)
         at = lambda t, off: ctypes.c_void_p(0 if t is None else t.data_ptr() + off)   # noqa: E731
         for m0, n in self._chunks():
-            for t in range(int(t_begin), int(t_end)):
-                rc = step(ctypes.byref(self.model), n, N, self._ptr(drive0), self.n_steps, t, at(self.r, m0 * w),
-                          at(self.q, m0 * w), at(self.R, m0 * w), at(self.S, m0 * w), ctypes.c_void_p(0), at(row, m0 * w),
-                          1, at(self.T_stats, (m0 // 64) * self.n_steps * 4 * 8), st)
-                rc = rc or hist(1, n, N, at(row, m0 * w), lo_h, hi_h, nb, self._ptr(self.T_hist[t:t + 1]), st)
+            t = int(t_begin)
+            while t < t_end:
+                t1 = min(int(t_end), (t // S + 1) * S)
+                rc = run(ctypes.byref(self.model), n, N, self._ptr(ring["drive"]), self.n_steps, t, t1, at(self.r, m0 * w),
+                         at(self.q, m0 * w), at(self.R, m0 * w), at(self.S, m0 * w), ctypes.c_void_p(0), at(buf, m0 * w), S,
+                         at(self.T_stats, (m0 // 64) * self.n_steps * 4 * 8), st)
+                rc = rc or hist(t1 - t, n, N, at(buf[t % S], m0 * w), lo_h, hi_h, nb, self._ptr(self.T_hist[t:t1]), st)
                 if rc != _capi.OK:
                     return rc
-                if t in stored:
-                    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(self.device)):
-                        self.T[stored[t], m0:m0 + n].copy_(row[0, m0:m0 + n])
+                with torch.cuda.stream(cur):
+                    for tt in range(t, t1):
+                        if tt in stored:
+                            self.T[stored[tt], m0:m0 + n].copy_(buf[tt % S, m0:m0 + n])
+                t = t1
         return _capi.OK
 
     def _run_fused_streamed_hist(self, t_begin, t_end, stream):
@@ -373,17 +387,15 @@ class EnsembleEngine:
         for chunk i with T of every step stored into ring slot i % 2 (its own drive table: output row = t mod S);
         stream B waits for that chunk, histograms the slot's rows into T_hist[t:t+S] (fiveeq_hist_rows_*) and copies
         the rows of the engine's own stored years into self.T; stream A reuses a slot only after B has drained it.
-        The fused kernel is VALU-bound and the histogram pass is a read-once stream, so the two overlap."""
+        The pass also returns the rows' moments, so the fused kernel runs without in-kernel statistics.  (Measured: the
+        two streams do not hide the pass — it takes wave slots from the fused kernel — the pipeline costs the sum of its
+        parts, +18 % at 12.5M fp32 members)"""
         if self.C is not None:
             raise RuntimeError("streamed histograms carry T only: build the engine with store_concentrations=False "
                                "(or store_trajectory=False), or use mode='tiled'")
         N, S = self.n_members, self.hist_ring_steps
         dev = self.device
-        if self._ring is None or "buf" not in self._ring:
-            drive = self.drive.clone()
-            drive[:, 7] = torch.arange(self.n_steps, device=dev, dtype=torch.int64).remainder(S).to(self.dtype)
-            self._ring = dict(self._ring or {}, drive=drive, buf=torch.empty((2, S, N), dtype=self.dtype, device=dev),
-                              side=torch.cuda.Stream(device=dev), drained=[torch.cuda.Event(), torch.cuda.Event()])
+        self._hist_ring()
         ring = self._ring
         main = stream if stream is not None else torch.cuda.current_stream(dev)
         side = ring["side"]

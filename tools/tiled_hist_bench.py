@@ -72,17 +72,16 @@ def main():
                   f"{t / t_fused - 1:+.1%} vs fused   ring {2 * S * N * (4 if a.dtype == 'f32' else 8) / 1e9:.2f} GB")
         assert eng.T_hist.sum(1).min().item() == N
         del eng
-    # the north-star per-step form with the same histograms: each step launch followed by a histogram launch over the
-    # T row it has just written (one scratch row, read back out of the Infinity Cache while it is still there)
+    # the north-star per-step form with the same histograms: S step launches (enqueued from C) store T into a ring strip,
+    # then one histogram launch over those S rows
     ps = EnsembleEngine(p, N, E, dtype=dt, store_trajectory=False, collect_stats=True)
     t_ps = timed(ps, 1, mode="per_step")
     del ps
     ph = EnsembleEngine(p, N, E, dtype=dt, store_trajectory=False, collect_stats=True, hist=(-2.0, 12.0, 4096))
     t_ph = timed(ph, 1, mode="per_step")
     assert ph.T_hist.sum(1).min().item() == N
-    del ph
     print(f"  per-step kernel (stats only)  {t_ps / a.steps * 1e6:9.2f} us/step")
-    print(f"  per-step kernel + histogram of each step's row, 4096 bins {t_ph / a.steps * 1e6:9.2f} us/step  "
+    print(f"  per-step kernel + histograms (ring of {ph.hist_ring_steps} steps), 4096 bins {t_ph / a.steps * 1e6:9.2f} us/step  "
           f"{t_ph / t_ps - 1:+.1%} vs per-step")
     if a.small:
         N2 = 10_000
