@@ -32,10 +32,18 @@ eng = EnsembleEngine(p, N, E, dtype=torch.float32, device="cuda:0", output_steps
                      store_concentrations=False, collect_stats=True, hist=(LO, HI, NB))
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-eng.run(mode=MODE)
+eng.run(mode=MODE)                                   # first pass: allocates the ring, loads the code objects
 torch.cuda.synchronize()
 t3 = time.perf_counter()
+eng.reset_state()
+eng.T_hist.zero_()
+torch.cuda.synchronize()
+t3a = time.perf_counter()
+eng.run(mode=MODE)                                   # steady state
+torch.cuda.synchronize()
+t3b = time.perf_counter()
 st = eng.stats()
+t3c = time.perf_counter()
 pct, tot = histogram_percentiles(eng.T_hist, LO, HI, (5.0, 50.0, 95.0))
 torch.cuda.synchronize()
 t4 = time.perf_counter()
@@ -46,9 +54,9 @@ mem = torch.cuda.max_memory_allocated() / 1e9
 print(f"members {N} (rank 3 of 8 of {N_TOTAL}), fp32, 750 steps, 3 gases, mode {MODE}")
 print(f"  GPU : shard of the Latin hypercube drawn on the device {t1 - t0:.3f} s; allocation {t2 - t1:.3f} s; "
       f"peak device memory {mem:.2f} GB (a stored T[750][N] alone would be {750 * N * 4 / 1e9:.1f} GB)")
-print(f"  GPU : run incl. per-step moments and in-loop 750 x {NB}-bin histograms {t3 - t2:.3f} s = "
-      f"{N * 750 / (t3 - t2):.3e} member-timesteps/s")
-print(f"  GPU : all-step percentiles from the histograms {t4 - t3:.4f} s; exact percentiles of 3 stored years by "
+print(f"  GPU : run incl. per-step moments and in-loop 750 x {NB}-bin histograms: first pass {t3 - t2:.3f} s, repeated "
+      f"{t3b - t3a:.3f} s = {N * 750 / (t3b - t3a):.3e} member-timesteps/s")
+print(f"  GPU : all-step percentiles from the histograms {t4 - t3c:.4f} s; exact percentiles of 3 stored years by "
       f"selection {t5 - t4:.4f} s")
 for row, t in enumerate((249, 499, 749)):
     print(f"  step {t}: mean {st['mean'][t].item():.4f} K, p05/p50/p95 histogram "
