@@ -597,6 +597,50 @@ def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
         assert np.abs(hp.cpu().numpy() - np.percentile(T_or, (5.0, 50.0, 95.0), axis=1).T).max() < tol
 
 
+def test_randomized_launch_shapes_and_histogram_specs(gpu):
+    """60 random combinations of ensemble size (around the 64 / 256 / 1024 block edges), step sub-ranges, steps per
+    launch, dtype, layout and histogram specification: tiled / K-step / streamed results must equal the fused kernel's
+    bit for bit, and every in-loop histogram the histogram of the stored rows."""
+    rng = np.random.default_rng(2026)
+    edges = [1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 2047, 2049, 3000, 5000]
+    for case in range(60):
+        N = int(rng.choice(edges)) if rng.random() < 0.7 else int(rng.integers(1, 6000))
+        n_steps = int(rng.integers(1, 70))
+        t0 = int(rng.integers(0, n_steps))
+        t1 = int(rng.integers(t0 + 1, n_steps + 1))
+        kind, G = (("multigas", 3), ("co2", 1))[int(rng.integers(0, 2))]
+        td = (torch.float64, torch.float32)[int(rng.integers(0, 2))]
+        nb = int(rng.choice([1, 2, 3, 17, 512, 1000, 4095, 4096]))
+        lo = float(rng.uniform(-3.0, 0.3))
+        hi = lo + float(rng.uniform(0.05, 9.0))
+        p = prm.sample_ensemble(prm.default_params(kind), N, seed=case)
+        E = emi.rcp_like_emissions(750, G)[200:200 + n_steps] * float(rng.uniform(0.5, 2.5))
+        ref = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=True)
+        ref.run(0, t0, mode="fused")                                  # a common, non-trivial starting state
+        state = ref.state_dict(include_outputs=False)
+        ref.run(t0, t1, mode="fused")
+        want_hist = ref.T_histogram(lo, hi, nb, rows=list(range(t0, t1)))
+        k_tile = int(rng.integers(0, 9))
+        for mode, k in (("tiled", k_tile), ("fused", None), ("per_step", None), ("ksteps", int(rng.integers(1, 20)))):
+            eng = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=True,
+                          hist=None if mode == "ksteps" else (lo, hi, nb), hist_ring_steps=int(rng.integers(1, 12)))
+            eng.load_state_dict(state)
+            k_use = min(k, eng.tile_steps()) if mode == "tiled" else k
+            eng.run(t0, t1, mode=mode, k_steps=k_use)
+            torch.cuda.synchronize()
+            what = (case, N, n_steps, t0, t1, kind, td, nb, mode, k_use)
+            assert torch.equal(eng.R, ref.R) and torch.equal(eng.S, ref.S), what
+            assert torch.equal(eng.T[t0:t1], ref.T[t0:t1]), what
+            if mode != "ksteps":
+                assert torch.equal(eng.T_hist[t0:t1], want_hist), what
+                assert int(eng.T_hist[:t0].sum()) == 0 and int(eng.T_hist[t1:].sum()) == 0, what
+            a, b = eng.stats_sums(t0, t1), ref.stats_sums(t0, t1)
+            assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]), what
+            assert torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-11, atol=1e-9), what
+            eng.close()
+        ref.close()
+
+
 def test_in_loop_histogram_survives_many_blocks_per_workgroup(gpu):
     """More than 63 member blocks per persistent workgroup (one workgroup per CU: > CUs x 63 x 1024 = 16.5M members)
     forces the intermediate LDS flush of the packed 16-bit counters; a 1-bin histogram concentrates every member
