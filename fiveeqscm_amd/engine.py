@@ -9,7 +9,8 @@ Data layout in HBM (struct-of-arrays over members; N = members of this shard):
     drive  [n_steps, 8]   shared: E_g, cumulative E_g before the step, F_ext, output row
     C      [n_rows, G, N]    concentrations of the stored steps (all steps, a selection, or none)
     T      [n_rows, N]       temperature of the stored steps
-    T_stats[W, n_steps, 4]   optional per-wave (sum, sum^2, min, max) of T, W = ceil(N/64), fp64
+    T_stats[W, n_steps, 4]   optional per-wave (sum, sum^2, min, max) of T, W = ceil(N/64), fp64 (0.5 B per member-step:
+                             allocated by the first run that writes wave records, not at construction)
     T_hist [n_steps, n_bins] optional fixed-bin histogram of T for EVERY step, accumulated inside the
                              time loop by the tiled kernel (run(mode="tiled")), int64
 
@@ -136,8 +137,8 @@ class EnsembleEngine:
             self.cumE = torch.zeros((G, N), dtype=dt_, device=dev) if self.concentration_driven else None
             self.E = self.C if self.concentration_driven else None
             self.n_waves = int(self.lib.fiveeq_stats_waves(N))
-            self.T_stats = (torch.zeros((self.n_waves, self.n_steps, 4), dtype=torch.float64, device=dev)
-                            if collect_stats else None)
+            self.collect_stats = bool(collect_stats)
+            self.T_stats = None          # per-wave records: 4.7 GB at 12.5M members x 750 steps, so allocated on demand
             # per-step (count, sum, sum^2, min, max) produced by the streamed histogram pass instead of the kernels
             self._step_sums = (torch.zeros((self.n_steps, 5), dtype=torch.float64, device=dev) if collect_stats else None)
             self._step_sums_valid = np.zeros(self.n_steps, dtype=bool)
@@ -227,6 +228,8 @@ class EnsembleEngine:
         self.t_next = int(state.get("t_next", 0))
         if "_step_sums_valid" in state:
             self._step_sums_valid[:] = np.asarray(state["_step_sums_valid"], dtype=bool)
+        if "T_stats" in state:
+            self._wave_stats()                                   # the checkpoint carries wave records: make room for them
         for name in ("T_stats", "T_hist", "C", "T", "_step_sums"):
             dst = getattr(self, name)
             if dst is not None and name in state:
@@ -234,6 +237,13 @@ class EnsembleEngine:
                 if src.shape != tuple(dst.shape):
                     raise ValueError(f"{name}: checkpoint shape {src.shape}, engine {tuple(dst.shape)}")
                 dst.copy_(torch.from_numpy(src).to(dst.dtype))
+
+    def _wave_stats(self):
+        """The per-wave record buffer of the in-kernel statistics, allocated by the first launch that writes it (the
+        streamed histogram pipeline takes its moments from the histogram pass and never needs it)."""
+        if self.collect_stats and self.T_stats is None:
+            self.T_stats = torch.zeros((self.n_waves, self.n_steps, 4), dtype=torch.float64, device=self.device)
+        return self.T_stats
 
     # -- launches ----------------------------------------------------------------------
     def _stream(self, stream=None):
@@ -273,11 +283,13 @@ class EnsembleEngine:
     def step(self, t, stream=None):
         """One timestep = one kernel launch (asynchronous)."""
         if self.concentration_driven:
+            self._wave_stats()
             with torch.cuda.device(self.device):
                 _capi.check(self.lib, self._run_inverse(t, t + 1, stream))
             return
         N = self.n_members
         fn = getattr(self.lib, f"fiveeq_step_{self._sfx}")
+        self._wave_stats()
         with torch.cuda.device(self.device):
             rc = fn(ctypes.byref(self.model), N, N, self._ptr(self.drive), self.n_steps, int(t),
                     self._ptr(self.r), self._ptr(self.q), self._ptr(self.R), self._ptr(self.S),
@@ -303,6 +315,8 @@ class EnsembleEngine:
             k_steps = self.auto_k_steps() if k_steps is None else int(k_steps)
             mode = "per_step" if k_steps <= 1 else "ksteps"
         with torch.cuda.device(self.device):
+            if not (mode == "fused" and self.T_hist is not None and not self.concentration_driven):
+                self._wave_stats()
             if self.concentration_driven:
                 rc = self._run_inverse(t_begin, t_end, stream)
             elif mode == "per_step" and self.T_hist is not None:
@@ -461,6 +475,7 @@ class EnsembleEngine:
         plans = self._plans.get(key)
         if plans is None:
             plans = []
+            self._wave_stats()
             fn = getattr(self.lib, f"fiveeq_plan_create_{self._sfx}")
             with torch.cuda.device(self.device):
                 for m0, n in self._chunks():
@@ -488,14 +503,16 @@ class EnsembleEngine:
         per-wave records the kernels wrote, or, for steps that ran through the streamed histogram pipeline
         (mode='fused' with hist=), as returned by that pass.  Additive across shards
         (fiveeqscm_amd.distributed.reduce_stats)."""
-        if self.T_stats is None:
+        if not self.collect_stats:
             raise RuntimeError("engine was built with collect_stats=False")
         t_end = self.n_steps if t_end is None else int(t_end)
-        s = self.T_stats[:, t_begin:t_end]                      # [W, n, 4]
+        valid = self._step_sums_valid[t_begin:t_end]
+        if valid.all():                                          # everything came from the histogram pass
+            return self._step_sums[t_begin:t_end].clone()
+        s = self._wave_stats()[:, t_begin:t_end]                 # [W, n, 4]
         cnt = torch.full((s.shape[1],), float(self.n_members), dtype=torch.float64, device=s.device)
         out = torch.stack([cnt, s[:, :, 0].sum(0), s[:, :, 1].sum(0), s[:, :, 2].min(0).values,
                            s[:, :, 3].max(0).values], dim=1)
-        valid = self._step_sums_valid[t_begin:t_end]
         if valid.any():
             pick = torch.from_numpy(valid).to(out.device)
             out[pick] = self._step_sums[t_begin:t_end][pick]
@@ -532,7 +549,7 @@ class EnsembleEngine:
         w = 8 if self.dtype == torch.float64 else 4
         G, SP = self.n_gas, self.sum_pools
         out = ((G if self.C is not None else 0) + 1) * self.n_rows / self.n_steps      # stored rows only
-        extra = (32.0 / 64.0) if self.T_stats is not None else 0.0   # one 32-B stats record per wave
+        extra = (32.0 / 64.0) if self.collect_stats else 0.0          # one 32-B stats record per wave
         if mode == "fused":
             return w * (out + (2 * SP + 3 * G + 6) / self.n_steps) + extra
         if mode in ("ksteps", "tiled"):

@@ -38,6 +38,13 @@ python3 $R/tools/pmc_valu.py $OUT/sq_counters_step_f32_4M.csv $OUT/valu.json 1 4
 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_co2 -- python3 $R/tools/pmc_workload.py 1000000 co2 > $OUT/pmc_sqa_co2.log 2>&1
 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_co2_fused -- python3 $R/tools/pmc_workload_fused.py 1000000 f64 96 8 co2 > $OUT/pmc_sqa_co2_fused.log 2>&1
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_co2_f64_1M.csv $OUT/valu.json 96 1000000 8 $OUT/pmc_sqa_co2 $OUT/pmc_sqa_co2_fused > /dev/null
+echo "== the streamed histogram pipeline under --kernel-trace --stats; LDS conflicts of the histogram kernels; fused traffic =="
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_config5_demo -- python3 $R/tools/config5_demo.py > $OUT/trace_config5_demo.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_lds_hist -- python3 $R/tools/pmc_workload_fused.py 4000000 f32 96 8 > $OUT/pmc_lds_hist.log 2>&1
+python3 $R/tools/pmc_valu.py $OUT/sq_counters_lds_f32_4M.csv $OUT/lds_valu_scratch.json 96 4000000 8 $OUT/pmc_lds_hist > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_fused -- python3 $R/tools/pmc_workload_fused_traffic.py > $OUT/pmc_fetch_fused.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_fused -- python3 $R/tools/pmc_workload_fused_traffic.py > $OUT/pmc_write_fused.log 2>&1
+python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_fused $OUT/pmc_write_fused 134217728 fused:f64:1000000 $OUT/traffic.json fused > /dev/null
 if [ -z "$QUICK" ]; then
 echo "== other bench lines =="
 python3 $R/bench.py --no-cpu-baseline --mode fused > $OUT/bench_config3_fused.json 2>/dev/null

@@ -7,13 +7,16 @@ corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
     byte count: n*8 read, n*8 written, buffers far beyond the 256 MiB Infinity Cache) IN THE SAME PASS
     and scale the step kernel's counters by (known bytes / counted bytes) of the copy.
 
-    python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <copy_elems> <key> [out.json]
+    python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <copy_elems> <key> [out.json] [step|fused]
 """
 import csv
 import glob
 import json
 import os
 import sys
+
+
+KERNEL = "fiveeq::step_kernel"
 
 
 def per_kernel(dirname, counter):
@@ -25,7 +28,7 @@ def per_kernel(dirname, counter):
                 if row["Counter_Name"] != counter:
                     continue
                 name = row["Kernel_Name"]
-                key = "step" if "fiveeq::step_kernel" in name else ("copy" if "fiveeq::stream_copy_kernel" in name else None)
+                key = "step" if KERNEL in name else ("copy" if "fiveeq::stream_copy_kernel" in name else None)
                 if key:
                     acc.setdefault(key, []).append(float(row["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
@@ -34,6 +37,9 @@ def per_kernel(dirname, counter):
 def main():
     fetch_dir, write_dir, copy_elems, key = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     out_path = sys.argv[5] if len(sys.argv) > 5 else None
+    global KERNEL
+    if len(sys.argv) > 6 and sys.argv[6] == "fused":
+        KERNEL = "fiveeq::fused_kernel"
     f = per_kernel(fetch_dir, "FETCH_SIZE")
     w = per_kernel(write_dir, "WRITE_SIZE")
     known = copy_elems * 8.0
