@@ -126,7 +126,9 @@ def test_gloo_world2_summary_exchange(n_total):
 
 
 def test_selection_percentiles_edge_cases():
-    """exact_percentiles: ties, constant rows, tiny rows, fp32 rows kept in fp32 on the wire."""
+    """exact_percentiles (the multi-rank path, called directly) and gather_summary (one rank: sort): ties, constant
+    rows, tiny rows, fp32 rows kept in fp32 on the wire."""
+    from fiveeqscm_amd.distributed import exact_percentiles
     rng = np.random.default_rng(5)
     for n in (1, 2, 5, 1000, 200_001):
         x = np.stack([rng.normal(size=n), rng.uniform(size=n) ** 3, np.full(n, 2.5), np.round(rng.normal(size=n), 1)])
@@ -137,6 +139,9 @@ def test_selection_percentiles_edge_cases():
             want = np.percentile(xs.astype(np.float64), (0.0, 5.0, 50.0, 95.0, 100.0, 33.3), axis=1).T
             np.testing.assert_allclose(out["percentiles"].numpy(), want, rtol=1e-14, atol=0)
             assert st["bytes_to_root"] == 0
+            t = torch.from_numpy(xs)
+            sel = exact_percentiles(t, (0.0, 5.0, 50.0, 95.0, 100.0, 33.3), t.min(1).values.double(), t.max(1).values.double(), n)
+            np.testing.assert_allclose(sel.numpy(), want, rtol=1e-14, atol=0)
 
 
 # ---- BASELINE configs[3] rehearsed at world size 8 (CPU, gloo): every rank computes ONLY its shard of the

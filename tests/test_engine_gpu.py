@@ -1021,3 +1021,22 @@ def test_full_size_config4_shard_rank3_of_8(gpu, chunk):
     from fiveeqscm_amd.distributed import gather_summary
     s = gather_summary(eng.T[2:3], percentiles=(5.0, 50.0, 95.0))
     np.testing.assert_allclose(s["percentiles"].cpu().numpy()[0], np.percentile(T_end, (5.0, 50.0, 95.0)), rtol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_percentile_selection_on_device_rows(gpu, dtype):
+    """distributed.exact_percentiles on CUDA rows (the path RCCL runs take): histograms by the engine's HIP kernel,
+    candidates by value with a one-bin margin — exact against NumPy, including ties, a constant row and heavy tails."""
+    from fiveeqscm_amd.distributed import exact_percentiles, gather_summary
+    rng = np.random.default_rng(9)
+    n = 1_000_003
+    x = np.stack([rng.normal(2.0, 0.7, n), rng.uniform(size=n) ** 6, np.full(n, -1.25), np.round(rng.normal(size=n), 2),
+                  rng.standard_cauchy(n)])
+    xt = torch.from_numpy(x).to("cuda:0", dtype)
+    xs = xt.double().cpu().numpy()
+    pct = (0.0, 0.1, 5.0, 50.0, 95.0, 99.9, 100.0)
+    st = {}
+    got = exact_percentiles(xt, pct, xt.min(1).values.double(), xt.max(1).values.double(), n, stats=st)
+    np.testing.assert_allclose(got.cpu().numpy(), np.percentile(xs, pct, axis=1).T, rtol=1e-13, atol=0)
+    one = gather_summary(xt, percentiles=pct)                   # one rank: the sort path
+    np.testing.assert_allclose(one["percentiles"].cpu().numpy(), np.percentile(xs, pct, axis=1).T, rtol=1e-13, atol=0)
