@@ -175,6 +175,7 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
     gmin/gmax [K] fp64: global extrema (from the merged moments); n_total: members over all ranks.
     Returns [K, P] fp64 on rank `dst`, None elsewhere.  `stats`, if a dict, receives bytes_to_root / allreduce_bytes."""
     dist, rank, world = _dist(group)
+    rows = rows.contiguous()
     K, n_local = rows.shape
     P = len(percentiles)
     dev = rows.device

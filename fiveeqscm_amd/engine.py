@@ -352,11 +352,12 @@ class EnsembleEngine:
     def _hist_ring(self):
         """Two-slot ring [2, S, N] of T rows + the drive table whose output row is t mod S (shared by the streamed
         pipelines of modes 'fused' and 'per_step')."""
-        N, S, dev = self.n_members, self.hist_ring_steps, self.device
-        if self._ring is None:
+        N, S, dev = self.n_members, max(1, min(int(self.hist_ring_steps), self.n_steps)), self.device
+        if self._ring is None or self._ring["S"] != S:       # (re)built whenever hist_ring_steps changed: the kernels are
+            torch.cuda.synchronize(dev)                      # told n_rows = S and must find S rows behind the pointer
             drive = self.drive.clone()
             drive[:, 7] = torch.arange(self.n_steps, device=dev, dtype=torch.int64).remainder(S).to(self.dtype)
-            self._ring = {"drive": drive, "buf": torch.empty((2, S, N), dtype=self.dtype, device=dev),
+            self._ring = {"S": S, "drive": drive, "buf": torch.empty((2, S, N), dtype=self.dtype, device=dev),
                           "side": torch.cuda.Stream(device=dev), "drained": [torch.cuda.Event(), torch.cuda.Event()]}
         return self._ring
 
@@ -368,8 +369,9 @@ class EnsembleEngine:
         if self.C is not None:
             raise RuntimeError("per-step histograms carry T only: build the engine with store_concentrations=False "
                                "(or store_trajectory=False), or use mode='tiled'")
-        N, S = self.n_members, self.hist_ring_steps
+        N = self.n_members
         ring = self._hist_ring()
+        S = ring["S"]
         buf = ring["buf"][0]
         run = getattr(self.lib, f"fiveeq_run_{self._sfx}")
         hist = getattr(self.lib, f"fiveeq_hist_rows_{self._sfx}")
@@ -407,10 +409,10 @@ class EnsembleEngine:
         if self.C is not None:
             raise RuntimeError("streamed histograms carry T only: build the engine with store_concentrations=False "
                                "(or store_trajectory=False), or use mode='tiled'")
-        N, S = self.n_members, self.hist_ring_steps
+        N = self.n_members
         dev = self.device
-        self._hist_ring()
-        ring = self._ring
+        ring = self._hist_ring()
+        S = ring["S"]
         main = stream if stream is not None else torch.cuda.current_stream(dev)
         side = ring["side"]
         side.wait_stream(main)                   # T_hist / self.T may have been touched on the caller's stream

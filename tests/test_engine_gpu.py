@@ -561,6 +561,7 @@ def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
     strm = _engine(p, N, E, dtype=td, output_steps=[3, 50, n_steps - 1], store_concentrations=False, collect_stats=True,
                    hist=(lo, hi, nb), hist_ring_steps=7)      # streamed pipeline: fused kernel + ring + second stream
     strm.run(0, 33, mode="fused")
+    strm.hist_ring_steps = 11                                  # changed between runs: the ring is rebuilt, not overrun
     strm.run(33, n_steps, mode="fused")                        # resumed mid-chunk
     pers = _engine(p, N, E, dtype=td, output_steps=[3, 50], store_concentrations=False, collect_stats=True,
                    hist=(lo, hi, nb), chunk_members=256 if N > 600 else 0)     # per-step kernel + histogram of each row
