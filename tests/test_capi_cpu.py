@@ -160,3 +160,31 @@ def test_latin_hypercube_is_stratified_and_seeded():
     assert s["r0"].shape == (3, 5000) and s["q"].shape == (2, 5000)
     r0c = np.asarray(prm.default_params("multigas")["r0"])[:, None]
     assert np.all(s["r0"] >= 0.8 * r0c - 1e-12) and np.all(s["r0"] <= 1.2 * r0c + 1e-12)
+
+
+def test_new_entry_points_validate_on_the_host():
+    """ABI v4 additions: K-steps, tiled + in-loop histograms, histogram pass with moments.  Bad arguments return on the
+    host (fake pointers are never dereferenced, nothing is launched)."""
+    lib = _capi.load()
+    m = prm.make_model(prm.default_params("multigas"))
+    p = ctypes.c_void_p(0x1000)
+    common = (ctypes.byref(m), 8, 8, p, 4, 0, 4, p, p, p, p, None, None, 0, None)
+    assert lib.fiveeq_run_ksteps_f64(*common, 0, None) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
+    assert lib.fiveeq_run_ksteps_f32(*common, -3, None) == _capi.E_INVALID
+    tiled = lambda k, lo, hi, nb, hist: lib.fiveeq_run_tiled_f64(*common, k, lo, hi, nb, hist, None)   # noqa: E731
+    assert tiled(0, 0.0, 1.0, 0, p) == _capi.E_INVALID and b"n_bins" in lib.fiveeq_last_error()
+    assert tiled(0, 0.0, 1.0, 5000, p) == _capi.E_INVALID
+    assert tiled(0, 1.0, 1.0, 64, p) == _capi.E_INVALID and b"lo < hi" in lib.fiveeq_last_error()
+    assert tiled(0, 0.0, float("inf"), 64, p) == _capi.E_INVALID
+    assert tiled(33, 0.0, 1.0, 0, None) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
+    assert tiled(lib.fiveeq_tile_steps_f64(4096) + 1, 0.0, 1.0, 4096, p) == _capi.E_INVALID
+    # the LDS budget: K x 8 KiB of histogram beside the kernel's statistics tiles and drive table
+    assert lib.fiveeq_tile_steps_f64(4096) == 11 and lib.fiveeq_tile_steps_f32(4096) == 15
+    assert lib.fiveeq_tile_steps_f64(0) == 32 and lib.fiveeq_tile_steps_f32(1024) == 32
+    assert lib.fiveeq_tile_steps_f64(-1) == 0 and lib.fiveeq_tile_steps_f32(4097) == 0
+    stats = lambda rows, moments: lib.fiveeq_hist_rows_stats_f32(2, 100, 100, rows, 0.0, 1.0, 16, p, moments, None)   # noqa: E731
+    assert stats(p, None) == _capi.E_INVALID and b"moments" in lib.fiveeq_last_error()
+    assert stats(None, p) == _capi.E_INVALID
+    assert lib.fiveeq_hist_rows_chunks(0, 100) == 0 and lib.fiveeq_hist_rows_chunks(1, 100) == 1
+    assert lib.fiveeq_hist_rows_chunks(1, 12_500_000) == 12_500_000 // 16384 + 1          # >= 16384 members per workgroup
+    assert lib.fiveeq_hist_rows_chunks(750, 12_500_000) == 3                              # ~2048 workgroups over all rows
