@@ -8,6 +8,16 @@
 // (only `emissions[0]*exp(-time)`, U_FaIR/concentrations.py:4-5); the function
 // split below follows the names it reserves at .coveragerc:12-19
 // (alpha_val, step_conc, step_forc, step_temp).  See include/fiveeq.h for the model.
+//
+// Kernels in this file:
+//   1   step_kernel        one timestep per launch — the north-star form; HBM-bound, A = w(2SP + 4G + 7) per member-step
+//   2   fused_kernel       time-fused (and, INV = true, concentration-driven); state in registers; VALU-bound
+//   2b  tile_kernel        time-tiled, persistent, with the T histogram of every step accumulated in LDS
+//   3   hfc_conc_kernel    the reference's one function over an ensemble
+//   4   hist_rows_kernel   fixed-bin histograms (+ moments) of rows: the pass of the streamed histogram pipelines
+//   5   lhs_kernel         shard-computable Latin hypercube (keyed Feistel bijection)
+//   diagnostics: stream_copy_kernel, stream_copy_wide_kernel, math_probe_kernel
+// All model arithmetic is member_step(): every kernel that steps the model gives the same bits.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

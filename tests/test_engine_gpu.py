@@ -642,6 +642,29 @@ def test_randomized_launch_shapes_and_histogram_specs(gpu):
         ref.close()
 
 
+def test_runs_are_reproducible_bit_for_bit(gpu):
+    """No run-to-run nondeterminism: the integer histogram atomics commute, every floating-point reduction has a fixed
+    order (per wave, then a fixed fold), and the two-stream pipeline is ordered by events."""
+    N, n_steps = 300_011, 60
+    p = prm.sample_ensemble_shard(prm.default_params("multigas"), N, device="cuda:0")
+    E = emi.rcp_like_emissions(750, 3)[260:260 + n_steps]
+    outs = []
+    for rep in range(3):
+        for mode in ("fused", "tiled", "per_step"):
+            eng = _engine(p, N, E, store_concentrations=False, output_steps=[10, 59], collect_stats=True,
+                          hist=(-1.0, 5.0, 4096), hist_ring_steps=16)
+            eng.run(mode=mode)
+            torch.cuda.synchronize()
+            outs.append((mode, eng.T_hist.clone(), eng.T.clone(), eng.R.clone(), eng.stats_sums().clone()))
+            eng.close()
+    for mode in ("fused", "tiled", "per_step"):
+        same = [o for o in outs if o[0] == mode]
+        for other in same[1:]:
+            for a, b in zip(same[0][1:], other[1:]):
+                assert torch.equal(a, b), mode
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][1], outs[2][1])      # and the same histogram in every mode
+
+
 def test_in_loop_histogram_survives_many_blocks_per_workgroup(gpu):
     """More than 63 member blocks per persistent workgroup (one workgroup per CU: > CUs x 63 x 1024 = 16.5M members)
     forces the intermediate LDS flush of the packed 16-bit counters; a 1-bin histogram concentrates every member
