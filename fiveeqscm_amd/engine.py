@@ -313,7 +313,14 @@ class EnsembleEngine:
         t_end = self.n_steps if t_end is None else int(t_end)
         if mode == "auto":
             k_steps = self.auto_k_steps() if k_steps is None else int(k_steps)
-            mode = "per_step" if k_steps <= 1 else "ksteps"
+            if k_steps <= 1:
+                mode = "per_step"
+            elif self.T_hist is not None:                # the K-step form that carries histograms is the tiled kernel
+                mode, k_steps = "tiled", min(k_steps, self.tile_steps())
+            else:
+                mode = "ksteps"
+        if self.T_hist is not None and mode in ("graph", "ksteps"):
+            raise ValueError(f"mode {mode!r} does not fill T_hist: use 'fused', 'tiled' or 'per_step' with hist=")
         with torch.cuda.device(self.device):
             if not (mode == "fused" and self.T_hist is not None and not self.concentration_driven):
                 self._wave_stats()

@@ -32,7 +32,8 @@ def timed(eng, **kw):
     return best / steps * 1e6
 
 
-for name in [None] + sorted(os.listdir(os.path.join(ROOT, "build_variants"))):
+VARIANTS = os.path.join(ROOT, "build_variants")
+for name in [None] + (sorted(os.listdir(VARIANTS)) if os.path.isdir(VARIANTS) else []):
     path = None if name is None else os.path.join(ROOT, "build_variants", name)
     if name is not None and not name.endswith(".so"):
         continue
