@@ -53,6 +53,21 @@ def main():
     inv = npo.run_inverse(conc, p, N)
     doc["cases"]["co2_inverse"] = {"n_members": N, "target_member": 0, "E": hx(inv["E"][cases.STEPS]),
                                    "T": hx(inv["T"][cases.STEPS]), "cumE_final": hx(inv["cumE"])}
+    # the same for the multi-gas set: all three gases driven by member 5's concentration pathways
+    p, N = cases.members("multigas")
+    E = cases.scenario("multigas")
+    conc = npo.run(E, p, N, keep=("C",))["C"][:, :, 5]         # [750, 3]
+    inv = npo.run_inverse(conc, p, N)
+    doc["cases"]["multigas_inverse"] = {"n_members": N, "target_member": 5, "E": hx(inv["E"][cases.STEPS]),
+                                        "T": hx(inv["T"][cases.STEPS]), "cumE_final": hx(inv["cumE"])}
+    # a run with a time step of half a year and an external forcing ramp (F_ext), CO2 only
+    p, N = cases.members("co2")
+    E2 = np.repeat(cases.scenario("co2"), 2, axis=0)[:600]     # 600 half-year steps
+    Fx = 0.002 * np.arange(600)
+    sub = npo.run(E2, p, N, F_ext=Fx, dt=0.5, keep=("C", "T"))
+    steps2 = [s for s in cases.STEPS if s < 600]
+    doc["cases"]["co2_halfyear_fext"] = {"n_members": N, "n_steps": 600, "dt": 0.5, "steps": steps2,
+                                         "C": hx(sub["C"][steps2]), "T": hx(sub["T"][steps2])}
     path = os.path.join(HERE, "fiveeq_golden.json")
     with open(path, "w") as fh:
         json.dump(doc, fh, separators=(",", ":"))

@@ -85,6 +85,26 @@ def test_inverse_mode_golden(golden):
     np.testing.assert_allclose(inv["E"][:, 0, 0], E[:, 0], rtol=1e-8, atol=1e-9)
 
 
+def test_more_golden_cases_multigas_inverse_and_half_year_steps(golden):
+    p, N = cases.members("multigas")
+    E = cases.scenario("multigas")
+    rec = golden["cases"]["multigas_inverse"]
+    conc = npo.run(E, p, N, keep=("C",))["C"][:, :, rec["target_member"]]
+    inv = npo.run_inverse(conc, p, N)
+    S = len(cases.STEPS)
+    np.testing.assert_allclose(inv["E"][cases.STEPS], _arr(rec["E"], (S, 3, N)), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(inv["T"][cases.STEPS], _arr(rec["T"], (S, N)), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(inv["E"][:, :, rec["target_member"]], E, rtol=1e-7, atol=1e-8)   # own pathway -> own emissions
+    p, N = cases.members("co2")
+    rec = golden["cases"]["co2_halfyear_fext"]
+    E2 = np.repeat(cases.scenario("co2"), 2, axis=0)[:600]
+    Fx = 0.002 * np.arange(600)
+    for runner in (npo.run, c_oracle.run):
+        out = runner(E2, p, N, F_ext=Fx, dt=0.5)
+        np.testing.assert_allclose(out["C"][rec["steps"]], _arr(rec["C"], (len(rec["steps"]), 1, N)), rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(out["T"][rec["steps"]], _arr(rec["T"], (len(rec["steps"]), N)), rtol=1e-13, atol=1e-15)
+
+
 # the bound asserted below; the measured worst case is printed by the test and recorded in DESIGN.md section 5
 MP_RTOL = 1e-13
 
@@ -156,3 +176,31 @@ def test_inverse_kernel_reproduces_the_golden_emissions(golden):
     S = len(cases.STEPS)
     np.testing.assert_allclose(eng.E.cpu().numpy(), _arr(rec["E"], (S, 1, N)), rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(eng.T.cpu().numpy(), _arr(rec["T"], (S, N)), rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_kernels_reproduce_the_extra_golden_cases(golden):
+    """Multi-gas inverse mode and a half-year time step with external forcing, through the C ABI."""
+    torch = pytest.importorskip("torch")
+    from fiveeqscm_amd.engine import EnsembleEngine
+    p, N = cases.members("multigas")
+    E = cases.scenario("multigas")
+    rec = golden["cases"]["multigas_inverse"]
+    conc = npo.run(E, p, N, keep=("C",))["C"][:, :, rec["target_member"]]
+    eng = EnsembleEngine(p, N, conc, device="cuda:0", output_steps=cases.STEPS, concentration_driven=True)
+    eng.run()
+    torch.cuda.synchronize()
+    S = len(cases.STEPS)
+    np.testing.assert_allclose(eng.E.cpu().numpy(), _arr(rec["E"], (S, 3, N)), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(eng.T.cpu().numpy(), _arr(rec["T"], (S, N)), rtol=1e-10, atol=1e-13)
+    p, N = cases.members("co2")
+    rec = golden["cases"]["co2_halfyear_fext"]
+    E2 = np.repeat(cases.scenario("co2"), 2, axis=0)[:600]
+    for mode in ("per_step", "fused", "tiled"):
+        eng = EnsembleEngine(p, N, E2, F_ext=0.002 * np.arange(600), dt=0.5, device="cuda:0", output_steps=rec["steps"])
+        eng.run(mode=mode)
+        torch.cuda.synchronize()
+        K = len(rec["steps"])
+        wantC, wantT = _arr(rec["C"], (K, 1, N)), _arr(rec["T"], (K, N))
+        assert np.all(np.abs(eng.C.cpu().numpy() - wantC) <= 1e-10 * np.abs(wantC) + 1e-13), mode
+        assert np.all(np.abs(eng.T.cpu().numpy() - wantT) <= 1e-10 * np.abs(wantT) + 1e-13), mode
