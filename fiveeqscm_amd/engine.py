@@ -549,6 +549,14 @@ class EnsembleEngine:
         _capi.check(self.lib, rc)
         return out
 
+    def hist_edge_counts(self):
+        """[n_steps, 2] int64: members counted in the first / last bin of T_hist per step.  Values outside [lo, hi) land
+        there, so non-zero entries at steps whose true extremes lie inside the range mean the range was too tight for
+        percentiles near that tail (compare with stats()['min'/'max'])."""
+        if self.T_hist is None:
+            raise RuntimeError("engine was built without hist=")
+        return torch.stack([self.T_hist[:, 0], self.T_hist[:, -1]], dim=1)
+
     # -- accounting ----------------------------------------------------------------------
     def bytes_per_member_step(self, mode="per_step", k_steps=None):
         """ALGORITHMIC HBM bytes per member-timestep:

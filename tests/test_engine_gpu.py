@@ -584,6 +584,7 @@ def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
     assert torch.equal(bare.T_hist, want) and torch.equal(bare.R, ref.R)
     assert eng.T_hist.sum(1).tolist() == [N] * n_steps
     assert int(want[-1, 0]) + int(want[-1, -1]) > 0 or N < 100           # the edge bins are exercised
+    assert torch.equal(eng.hist_edge_counts(), torch.stack([want[:, 0], want[:, -1]], dim=1))
     if dtype == "f64" and N >= 1000:
         from fiveeqscm_amd.distributed import histogram_percentiles
         wide = _engine(p, N, E, store_trajectory=False, hist=(-2.0, 12.0, nb))

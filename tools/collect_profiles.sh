@@ -56,6 +56,8 @@ python3 $R/bench.py --no-cpu-baseline --workload config2 --mode fused > $OUT/ben
 python3 $R/bench.py --no-cpu-baseline --workload config4 > $OUT/bench_config4_per_gpu_shard.json 2>/dev/null
 python3 $R/bench.py --no-cpu-baseline --workload config5 --dtype f32 --steps 300 > $OUT/bench_config5_f32_per_gpu_shard.json 2>/dev/null
 python3 $R/bench.py --no-cpu-baseline --dtype f32 > $OUT/bench_config3_f32.json 2>/dev/null
+python3 $R/bench.py --no-cpu-baseline --dtype f32 --mode fused > $OUT/bench_config3_f32_fused.json 2>/dev/null
+python3 $R/bench.py --no-cpu-baseline --workload config5 --dtype f32 --mode fused --no-trajectory > $OUT/bench_config5_f32_fused_no_trajectory.json 2>/dev/null
 echo "== sweeps =="
 python3 $R/tools/sweep.py --members 100000,250000,500000,1000000,2000000,4000000 --modes per_step,fused 2>&1 | grep -v amdgpu.ids > $OUT/sweep_members.txt
 python3 $R/tools/sweep.py --members 8000000 --scenario-steps 330 --modes per_step,fused 2>&1 | grep -v amdgpu.ids >> $OUT/sweep_members.txt
