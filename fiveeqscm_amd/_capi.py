@@ -10,11 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FIVEEQ_LIB_PATH selects another build of the same library (e.g. the host-sanitizer build of tools/sanitize_host.sh)
 LIB_PATH = os.environ.get("FIVEEQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_GAS = 3
 MAX_POOLS = 4
 N_BOX = 2
 DRIVE_STRIDE = 8
+LHS_MAX_TOTAL = 1 << 28
 
 OK = 0
 E_INVALID = -1
@@ -89,6 +90,8 @@ SIGNATURES = {
     "fiveeq_run_tiled_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
     "fiveeq_tile_steps_f64": (_i32, [_i32]),
     "fiveeq_tile_steps_f32": (_i32, [_i32]),
+    "fiveeq_tile_lds_bytes": (_i32, []),
+    "fiveeq_tile_attr_calls": (_i32, []),
     "fiveeq_lhs_rows_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p, _p]),
     "fiveeq_lhs_rows_host_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p]),
     "fiveeq_plan_launch": (ctypes.c_int, [_p, _p]),

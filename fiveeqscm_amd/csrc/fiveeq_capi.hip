@@ -250,6 +250,8 @@ int run_ksteps(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int
     RunArgs<T> a;
     if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
     if (k_steps < 1) return fail(FIVEEQ_E_INVALID, "k_steps=%d must be >= 1", k_steps);
+    if (t_begin == t_end) return FIVEEQ_OK;
+    if (k_steps > t_end - t_begin) k_steps = t_end - t_begin;      // also keeps t + k_steps inside int32
     for (int t = t_begin; t < t_end; t += k_steps)
         if (int rc = launch_fused<T, false>(a, t, t + k_steps < t_end ? t + k_steps : t_end, nullptr, (hipStream_t)stream))
             return rc;
@@ -257,7 +259,32 @@ int run_ksteps(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int
 }
 
 // ---- time-tiled persistent kernel with in-loop histograms ---------------------------------------
-constexpr int LDS_BYTES = 160 * 1024;
+// LDS a workgroup may use, from the device (hipDeviceAttributeMaxSharedMemoryPerBlock: 160 KiB on MI355X), asked once per
+// thread and device.  Without a device (the CPU build container, where only the argument checks run) the gfx950 figure is
+// assumed, so that fiveeq_tile_steps_* answers the same there.
+constexpr int GFX950_LDS_BYTES = 160 * 1024;
+struct DeviceFacts {
+    int dev = -1, cus = 256, lds_bytes = GFX950_LDS_BYTES;
+};
+const DeviceFacts& device_facts() {
+    static thread_local DeviceFacts f;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return f;                                           // no device: defaults (or the last device's facts)
+    }
+    if (dev != f.dev) {
+        int v = 0;
+        f.cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        f.lds_bytes = (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+                          ? v : GFX950_LDS_BYTES;
+        f.dev = dev;
+    }
+    return f;
+}
+int device_cus() { return device_facts().cus; }
+int device_lds_bytes() { return device_facts().lds_bytes; }
+
 template <typename T>
 constexpr int tile_static_lds() {
     return (int)(sizeof(T) * (TILE_MAX_STEPS * DRIVE_STRIDE + (TILE_BLOCK / 64) * STAT_STEPS * STAT_ROW) + sizeof(KModel<T>));
@@ -267,21 +294,36 @@ template <typename T>
 int tile_steps_max(int n_bins) {
     if (n_bins < 1) return TILE_MAX_STEPS;
     const int hw_bytes = ((n_bins + 1) / 2) * 4;
-    const int k = (LDS_BYTES - tile_static_lds<T>() - 512) / hw_bytes;
+    const int k = (device_lds_bytes() - tile_static_lds<T>() - 512) / hw_bytes;
     return k > TILE_MAX_STEPS ? TILE_MAX_STEPS : k;
 }
 
-int device_cus() {
-    static thread_local int cached_dev = -1, cached_cus = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (dev != cached_dev) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        cached_dev = dev;
-        cached_cus = cus;
+// A launch with more than 48 KiB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize raised on the kernel
+// first.  That is a property of (kernel instantiation, device), not of a launch: it is set ONCE per instantiation and
+// device, to the largest size this build can ask for (the device's LDS minus the kernel's static part), and remembered.
+int g_tile_attr_calls = 0;                                  // how often the attribute was really set (tests)
+template <typename T>
+int tile_prepare(int code, size_t dyn_needed) {
+    if (dyn_needed <= 48 * 1024) return FIVEEQ_OK;
+    static thread_local int done_dev[1000];                 // by layout code p0*100 + p1*10 + p2: device + 1 it is set for
+    const int dev = device_facts().dev;
+    if (code < 0 || code >= 1000) return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", code);
+    if (done_dev[code] == dev + 1) return FIVEEQ_OK;
+    const int dyn_max = device_lds_bytes() - tile_static_lds<T>();
+    switch (code) {
+#define X(p0, p1, p2)                                                                                        \
+    case (p0) * 100 + (p1) * 10 + (p2):                                                                      \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<T, p0, p1, p2>),               \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));                   \
+        break;
+        FIVEEQ_LAYOUTS(X)
+#undef X
+        default:
+            return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", code);
     }
-    return cached_cus;
+    ++g_tile_attr_calls;
+    done_dev[code] = dev + 1;
+    return FIVEEQ_OK;
 }
 
 template <typename T>
@@ -296,9 +338,6 @@ int launch_tile(const RunArgs<T>& a, int t_begin, int t_end, double lo, double i
 #define X(p0, p1, p2)                                                                                        \
     case (p0) * 100 + (p1) * 10 + (p2): {                                                                    \
         auto kfn = tile_kernel<T, p0, p1, p2>;                                                               \
-        if (dyn > 48 * 1024)                                                                                 \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));              \
         hipLaunchKernelGGL(kfn, grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, \
                            a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, hist);        \
     } break;
@@ -331,6 +370,7 @@ int run_tiled(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     if (k_steps < 0 || k_steps > k_max)
         return fail(FIVEEQ_E_INVALID, "k_steps=%d outside 0..%d (0 = largest that fits)", k_steps, k_max);
     if (k_steps == 0) k_steps = k_max;
+    if (int rc = tile_prepare<T>(a.code, (size_t)k_max * ((n_bins + 1) / 2) * 4)) return rc;
     for (int t = t_begin; t < t_end; t += k_steps)
         if (int rc = launch_tile<T>(a, t, t + k_steps < t_end ? t + k_steps : t_end, lo, inv_w, n_bins,
                                     reinterpret_cast<unsigned long long*>(hist), (hipStream_t)stream))
@@ -499,11 +539,16 @@ int fiveeq_run_tiled_f32(const fiveeq_model* model, int64_t n_members, int64_t l
     return run_tiled<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
                             T_stats, k_steps, hist_lo, hist_hi, n_bins, T_hist, stream);
 }
+int32_t fiveeq_tile_lds_bytes(void) { return device_lds_bytes(); }
+int32_t fiveeq_tile_attr_calls(void) { return g_tile_attr_calls; }
 int32_t fiveeq_tile_steps_f64(int32_t n_bins) { return n_bins < 0 || n_bins > fiveeq::HIST_MAX_BINS ? 0 : tile_steps_max<double>(n_bins); }
 int32_t fiveeq_tile_steps_f32(int32_t n_bins) { return n_bins < 0 || n_bins > fiveeq::HIST_MAX_BINS ? 0 : tile_steps_max<float>(n_bins); }
 
 static int lhs_check(int64_t n_total, int64_t m0, int64_t n_members, int32_t dim0, int32_t n_dim, int64_t ld) {
-    if (n_total < 1 || n_total > (1LL << 40)) return fail(FIVEEQ_E_INVALID, "n_total=%lld outside 1..2^40", (long long)n_total);
+    // 2^28: stratum (28 bits) + the 24-bit jitter placed mid-cell (25 fractional bits) is then an EXACT fp64 sum, so u lies
+    // strictly inside its stratum; beyond that the sum would round and could touch the stratum edge
+    if (n_total < 1 || n_total > FIVEEQ_LHS_MAX_TOTAL)
+        return fail(FIVEEQ_E_INVALID, "n_total=%lld outside 1..2^28", (long long)n_total);
     if (m0 < 0 || n_members < 0 || m0 + n_members > n_total)
         return fail(FIVEEQ_E_INVALID, "members [%lld, %lld) outside [0, %lld)", (long long)m0, (long long)(m0 + n_members),
                     (long long)n_total);

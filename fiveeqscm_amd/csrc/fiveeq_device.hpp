@@ -765,8 +765,8 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
 // into range), jitter a 24-bit counter-based hash placed mid-cell, so u lies strictly inside
 // stratum pi_k(m).  Pure function of (seed, dimension, m, n_total): any rank computes exactly its
 // own members, on its own device, and the design is the same for every world size.  Integer
-// arithmetic + one exact fp64 add + one correctly rounded division: params.lhs_rows (NumPy)
-// reproduces it bit for bit.
+// arithmetic + one fp64 add that is EXACT for n_total <= 2^28 (28 stratum bits + 25 jitter bits <= 53; the C ABI
+// refuses larger designs) + one correctly rounded division: params.lhs_rows (NumPy) reproduces it bit for bit.
 // ---------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint64_t lhs_mix64(uint64_t z) {      // splitmix64 finaliser
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;

@@ -14,6 +14,8 @@ step: summary statistics of T (or C) at selected output times, over ALL members 
 `torch.distributed` backend "nccl" is RCCL on ROCm; the same code runs on CPU tensors over gloo
 (tests/test_distributed.py).  The reference has no distributed code at all.
 """
+import os
+
 import torch
 
 
@@ -26,11 +28,28 @@ def shard_bounds(n_total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+# First-contact hook: with a process group of ONE rank the collectives below would all be skipped ("nothing to
+# exchange").  force_collectives(True) — or FIVEEQ_FORCE_COLLECTIVES=1 in the environment — makes every one of them
+# execute on the group's backend anyway, so that a one-GPU box can run the exact RCCL calls the multi-GPU summary makes
+# (all_gather fp64, all_reduce SUM int64 / MIN / MAX fp64, gather of a device tensor with a receive list) before the
+# first multi-GPU lease does (tests/test_distributed_gpu.py::test_rccl_first_contact_on_one_gpu).
+_FORCE = [os.environ.get("FIVEEQ_FORCE_COLLECTIVES", "") == "1"]
+
+
+def force_collectives(on=True):
+    """Run the exchange's collectives even in a one-rank group (see above).  Returns the previous setting."""
+    prev, _FORCE[0] = _FORCE[0], bool(on)
+    return prev
+
+
 def _dist(group):
+    """(dist module or None, rank, world, exchange) — `exchange` says whether the collectives run: more than one rank,
+    or a one-rank group with force_collectives on."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        return dist, dist.get_rank(group), dist.get_world_size(group)
-    return None, 0, 1
+        world = dist.get_world_size(group)
+        return dist, dist.get_rank(group), world, world > 1 or _FORCE[0]
+    return None, 0, 1, False
 
 
 def _comm_tensor(dist, group, x):
@@ -95,9 +114,9 @@ def reduce_stats(sums, group=None):
     """All-reduce the per-shard (count, sum, sum^2, min, max) records of every step over the ranks
     (three tiny collectives: SUM on the first three columns, MIN, MAX) and return the ensemble
     moments on every rank.  This is all a run without stored trajectories has to exchange."""
-    dist, _, world = _dist(group)
+    dist, _, _, exchange = _dist(group)
     sums = _comm_tensor(dist, group, sums).clone()
-    if world > 1:
+    if exchange:
         add, mn, mx = sums[:, :3].contiguous(), sums[:, 3].contiguous(), sums[:, 4].contiguous()
         dist.all_reduce(add, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
@@ -112,9 +131,9 @@ def histogram_percentiles(hist, lo, hi, percentiles=(5.0, 50.0, 95.0), group=Non
     bins) replaces gathering the members; percentiles are read off the cumulative counts with linear
     interpolation inside the bin, so the error is below one bin width w = (hi - lo)/n_bins for
     values inside [lo, hi).  Returns (percentiles [K, P] fp64, total counts [K]) on every rank."""
-    dist, _, world = _dist(group)
+    dist, _, _, exchange = _dist(group)
     h = _comm_tensor(dist, group, hist).clone()
-    if world > 1:
+    if exchange:
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
     n_bins = h.shape[1]
     w = (float(hi) - float(lo)) / n_bins
@@ -174,14 +193,14 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
     root sorts the few candidates and reads the order statistics off at (index - below).
     gmin/gmax [K] fp64: global extrema (from the merged moments); n_total: members over all ranks.
     Returns [K, P] fp64 on rank `dst`, None elsewhere.  `stats`, if a dict, receives bytes_to_root / allreduce_bytes."""
-    dist, rank, world = _dist(group)
+    dist, rank, world, exchange = _dist(group)
     rows = rows.contiguous()
     K, n_local = rows.shape
     P = len(percentiles)
     dev = rows.device
     lo, hi = [float(v) for v in gmin.tolist()], [float(v) for v in gmax.tolist()]
     counts = _row_histograms(rows, lo, hi, n_bins)
-    if world > 1:
+    if exchange:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     cdf = torch.cumsum(counts, dim=1)                                              # [K, n_bins], last = n_total
     pos = [float(p) / 100.0 * (n_total - 1) for p in percentiles]
@@ -213,7 +232,7 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
     payload = torch.cat(parts) if parts else rows.new_empty(0)
     size_t = torch.tensor(sizes, dtype=torch.int64, device=dev)
     below = below_local
-    if world > 1:
+    if exchange:
         dist.all_reduce(below, op=dist.ReduceOp.SUM, group=group)
         all_sizes = [torch.empty_like(size_t) for _ in range(world)]
         dist.all_gather(all_sizes, size_t, group=group)
@@ -259,15 +278,15 @@ def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats
     on rank `dst` it also holds 'percentiles' [K, len(percentiles)] over ALL members (None elsewhere) —
     exact (NumPy 'linear'), found by selection (see the module docstring).  `stats` (dict) receives
     'bytes_to_root' (candidate members the root received) and 'allreduce_bytes' (the histogram)."""
-    dist, rank, world = _dist(group)
+    dist, rank, world, exchange = _dist(group)
     rows = _comm_tensor(dist, group, rows.contiguous())
     mom = local_moments(rows)
-    if world > 1:
+    if exchange:
         parts = [torch.empty_like(mom) for _ in range(world)]
         dist.all_gather(parts, mom, group=group)
         mom = merge_moments(torch.stack(parts))
     n_total = int(round(float(mom[0, 0].item())))
-    if world == 1 and rows.shape[1] <= (1 << 21):
+    if not exchange and rows.shape[1] <= (1 << 21):
         # nothing to exchange and a moderate row: a device sort is as fast as anything (1.7 ms for 3 x 1M fp64 values
         # with the moments, warm).  Selection pays off when the alternative is moving every rank's rows, and on long
         # rows even on one rank (3 x 12.5M values: 2.6 ms against 16 ms).

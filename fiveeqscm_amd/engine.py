@@ -186,7 +186,9 @@ class EnsembleEngine:
 
     # -- state -------------------------------------------------------------------------
     def reset_state(self):
-        """Back to the initial condition (zeros, or the R0/S0 given at construction)."""
+        """Back to the initial condition (zeros, or the R0/S0 given at construction) — the run accumulators too:
+        `T_hist` ACCUMULATES over the runs that fill it (a step histogrammed twice counts twice), so it is zeroed here,
+        and the per-step moment records are marked not-yet-written."""
         if self._R0 is None:
             self.R.zero_()
         else:
@@ -197,28 +199,50 @@ class EnsembleEngine:
             self.S.copy_(torch.from_numpy(self._S0).to(self.dtype))
         if self.cumE is not None:
             self.cumE.zero_()
+        if self.T_hist is not None:
+            self.T_hist.zero_()
+        self._step_sums_valid[:] = False
         self.t_next = 0
 
-    def state_dict(self, include_outputs=True):
+    def state_dict(self, include_outputs="summaries"):
         """Checkpoint: everything a resumed run needs besides the (immutable) parameters and drive
         table — pools, thermal boxes, in inverse mode the per-member cumulative emissions, the index
-        `t_next` of the first step not yet run, and (include_outputs) what the run has accumulated so
-        far: T_stats, T_hist and the stored C/T rows — as host NumPy arrays (state in fp64).  Resume with
-        `load_state_dict` and `run(state["t_next"], ...)`: bit-identical to an uninterrupted run
+        `t_next` of the first step not yet run — as host NumPy arrays (state in fp64), plus, by `include_outputs`:
+          "summaries" (default)  what the run has REDUCED so far: `T_hist` ([n_steps, n_bins] int64, 24 MB at 750 x 4096)
+                                 and the per-step moment sums of steps [0, t_next) folded to [n_steps, 5] (30 KB) — small
+                                 whatever the ensemble size;
+          True                   also the raw buffers: per-wave records `T_stats` (0.5 B per member-step: 4.7 GB at
+                                 12.5M members x 750 steps) and the stored C/T rows ((G+1) w bytes per member and stored
+                                 step: 24 GB for 1M fp64 members x 750 steps) — sized like the run, so opt-in;
+          False                  the state only.
+        Resume with `load_state_dict` and `run(state["t_next"], ...)`: bit-identical to an uninterrupted run
         (checkpoint/resume)."""
+        if include_outputs not in (True, False, "summaries"):
+            raise ValueError("include_outputs must be True, False or 'summaries'")
         torch.cuda.synchronize(self.device)
         out = {"R": self.R.double().cpu().numpy(), "S": self.S.double().cpu().numpy(), "t_next": int(self.t_next)}
         if self.cumE is not None:
             out["cumE"] = self.cumE.double().cpu().numpy()
         if include_outputs:
-            for name in ("T_stats", "T_hist", "C", "T", "_step_sums"):
+            if self.T_hist is not None:
+                out["T_hist"] = self.T_hist.cpu().numpy()
+            if self.collect_stats:
+                sums = np.zeros((self.n_steps, 5), dtype=np.float64)
+                valid = np.zeros(self.n_steps, dtype=bool)
+                if self.t_next > 0:
+                    sums[:self.t_next] = self.stats_sums(0, self.t_next).cpu().numpy()
+                    valid[:self.t_next] = True
+                out["_step_sums"], out["_step_sums_valid"] = sums, valid
+        if include_outputs is True:
+            for name in ("T_stats", "C", "T"):
                 buf = getattr(self, name)
                 if buf is not None:
                     out[name] = buf.cpu().numpy()
-            out["_step_sums_valid"] = self._step_sums_valid.copy()
         return out
 
     def load_state_dict(self, state):
+        """Restore a checkpoint.  One WITHOUT summaries (include_outputs=False) restores the state only: the accumulators
+        of this engine (T_hist, per-step moments) are then cleared, because they describe a run this state is not from."""
         for name in ("R", "S") + (("cumE",) if self.cumE is not None else ()):
             dst = getattr(self, name)
             src = np.asarray(state[name], dtype=np.float64)
@@ -226,8 +250,11 @@ class EnsembleEngine:
                 raise ValueError(f"{name}: checkpoint shape {src.shape}, engine {tuple(dst.shape)}")
             dst.copy_(torch.from_numpy(src).to(self.dtype))
         self.t_next = int(state.get("t_next", 0))
-        if "_step_sums_valid" in state:
+        self._step_sums_valid[:] = False
+        if "_step_sums_valid" in state and self._step_sums is not None:
             self._step_sums_valid[:] = np.asarray(state["_step_sums_valid"], dtype=bool)
+        if self.T_hist is not None and "T_hist" not in state:
+            self.T_hist.zero_()
         if "T_stats" in state:
             self._wave_stats()                                   # the checkpoint carries wave records: make room for them
         for name in ("T_stats", "T_hist", "C", "T", "_step_sums"):
@@ -324,6 +351,8 @@ class EnsembleEngine:
         with torch.cuda.device(self.device):
             if not (mode == "fused" and self.T_hist is not None and not self.concentration_driven):
                 self._wave_stats()
+                # these launches write per-wave records: moments an earlier streamed pass left for the same steps are stale
+                self._step_sums_valid[int(t_begin):t_end] = False
             if self.concentration_driven:
                 rc = self._run_inverse(t_begin, t_end, stream)
             elif mode == "per_step" and self.T_hist is not None:
@@ -356,15 +385,16 @@ class EnsembleEngine:
         _capi.check(self.lib, rc)
         self.t_next = t_end
 
-    def _hist_ring(self):
-        """Two-slot ring [2, S, N] of T rows + the drive table whose output row is t mod S (shared by the streamed
-        pipelines of modes 'fused' and 'per_step')."""
+    def _hist_ring(self, slots=2):
+        """Ring [slots, S, N] of T rows + the drive table whose output row is t mod S (shared by the streamed pipelines:
+        mode 'fused' double-buffers, two slots; mode 'per_step' uses one)."""
         N, S, dev = self.n_members, max(1, min(int(self.hist_ring_steps), self.n_steps)), self.device
-        if self._ring is None or self._ring["S"] != S:       # (re)built whenever hist_ring_steps changed: the kernels are
-            torch.cuda.synchronize(dev)                      # told n_rows = S and must find S rows behind the pointer
+        if self._ring is None or self._ring["S"] != S or self._ring["buf"].shape[0] < slots:
+            torch.cuda.synchronize(dev)      # (re)built whenever hist_ring_steps changed: the kernels are told n_rows = S
+            self._ring = None                # and must find S rows behind the pointer
             drive = self.drive.clone()
             drive[:, 7] = torch.arange(self.n_steps, device=dev, dtype=torch.int64).remainder(S).to(self.dtype)
-            self._ring = {"S": S, "drive": drive, "buf": torch.empty((2, S, N), dtype=self.dtype, device=dev),
+            self._ring = {"S": S, "drive": drive, "buf": torch.empty((slots, S, N), dtype=self.dtype, device=dev),
                           "side": torch.cuda.Stream(device=dev), "drained": [torch.cuda.Event(), torch.cuda.Event()]}
         return self._ring
 
@@ -377,7 +407,7 @@ class EnsembleEngine:
             raise RuntimeError("per-step histograms carry T only: build the engine with store_concentrations=False "
                                "(or store_trajectory=False), or use mode='tiled'")
         N = self.n_members
-        ring = self._hist_ring()
+        ring = self._hist_ring(slots=1)
         S = ring["S"]
         buf = ring["buf"][0]
         run = getattr(self.lib, f"fiveeq_run_{self._sfx}")
@@ -562,17 +592,23 @@ class EnsembleEngine:
         """ALGORITHMIC HBM bytes per member-timestep:
         per_step:        w (2 SP + 4 G + 7)   [R,S read+write; r,q read; C,T write];
         fused:           w (G + 1) + w (2 SP + 3 G + 6) / n_steps;
-        ksteps / tiled:  w (G + 1) + w (2 SP + 3 G + 6) / k_steps  (state + parameters once per k_steps)."""
+        ksteps / tiled:  w (G + 1) + w (2 SP + 3 G + 6) / k_steps  (state + parameters once per k_steps).
+        With `hist=` the streamed pipelines of 'fused' and 'per_step' add the ring: T written by the step kernel and read
+        back by the histogram pass, 2 w per member-step, and 'fused' then reloads state + parameters once per
+        hist_ring_steps instead of once per run (its moments come from the pass: no wave records)."""
         w = 8 if self.dtype == torch.float64 else 4
         G, SP = self.n_gas, self.sum_pools
         out = ((G if self.C is not None else 0) + 1) * self.n_rows / self.n_steps      # stored rows only
         extra = (32.0 / 64.0) if self.collect_stats else 0.0          # one 32-B stats record per wave
+        ring = 2.0 * w if (self.T_hist is not None and mode in ("fused", "per_step")) else 0.0
+        if mode == "fused" and self.T_hist is not None:
+            return w * (out + (2 * SP + 3 * G + 6) / max(1, min(self.hist_ring_steps, self.n_steps))) + ring
         if mode == "fused":
             return w * (out + (2 * SP + 3 * G + 6) / self.n_steps) + extra
         if mode in ("ksteps", "tiled"):
             k = k_steps or (self.auto_k_steps() if mode == "ksteps" else self.tile_steps())
             return w * (out + (2 * SP + 3 * G + 6) / max(int(k), 1)) + extra
-        return w * (2 * SP + 3 * G + 6 + out) + extra
+        return w * (2 * SP + 3 * G + 6 + out) + extra + ring
 
 
 def run_ensemble(emissions, params, n_members, *, F_ext=None, dt=1.0, dtype=torch.float64, device=None,

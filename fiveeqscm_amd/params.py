@@ -255,6 +255,8 @@ def lhs_rows(n_total, dims, lo=0, hi=None, seed=LHS_SEED):
     """[len(dims), hi-lo] fp64: u_d(m) = (pi_d(m) + jitter_d(m)) / n_total for members lo <= m < hi of a
     Latin hypercube over n_total members; one member per stratum in every dimension."""
     hi = n_total if hi is None else hi
+    if not 1 <= n_total <= _capi.LHS_MAX_TOTAL:          # stratum (<= 28 bits) + mid-cell jitter (25 bits): an exact fp64 sum
+        raise ValueError(f"n_total={n_total} outside 1..2^28")
     if not 0 <= lo <= hi <= n_total:
         raise ValueError(f"members [{lo}, {hi}) outside [0, {n_total})")
     m = np.arange(lo, hi, dtype=np.uint64)

@@ -49,11 +49,12 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   4
+#define FIVEEQ_ABI_VERSION   5
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
 #define FIVEEQ_DRIVE_STRIDE  8   /* elements per step in the drive table, below */
+#define FIVEEQ_LHS_MAX_TOTAL (1LL << 28)   /* largest Latin-hypercube design (members): stratum + jitter stays an exact fp64 sum */
 
 #define FIVEEQ_OK             0
 #define FIVEEQ_E_INVALID     -1  /* bad argument (NULL pointer, size, range) */
@@ -207,6 +208,12 @@ int fiveeq_run_tiled_f32(const fiveeq_model *model, int64_t n_members, int64_t l
 /* largest k_steps the tiled kernel accepts for n_bins (0 = no histogram); 0 for an invalid n_bins */
 int32_t fiveeq_tile_steps_f64(int32_t n_bins);
 int32_t fiveeq_tile_steps_f32(int32_t n_bins);
+/* LDS bytes per workgroup the tile size is derived from: hipDeviceAttributeMaxSharedMemoryPerBlock of the calling
+ * thread's current device (160 KiB on MI355X; the same figure is assumed when no device is visible). */
+int32_t fiveeq_tile_lds_bytes(void);
+/* diagnostic: how many times the tiled kernel's dynamic-LDS limit (hipFuncSetAttribute) has been set so far — once per
+ * kernel instantiation and device, not per launch */
+int32_t fiveeq_tile_attr_calls(void);
 
 /* CONCENTRATION-DRIVEN (inverse) mode (the reference's module name
  * `concentrations` hints at it, no reference code exists).  drive[t][0..2] hold the TARGET
@@ -257,6 +264,8 @@ int64_t fiveeq_hist_rows_chunks(int32_t n_rows, int64_t n_members);
  * 24-bit counter-based hash in (0,1): exactly one member per stratum and dimension, and a pure
  * function of (seed, d, m, n_total) — every rank computes only its own members, on its own device,
  * and gets the same design whatever the world size.  out dev [n_dim][ld] fp64.
+ * 1 <= n_total <= FIVEEQ_LHS_MAX_TOTAL (2^28): up to there pi + jitter (28 + 25 bits) is an exact fp64 sum, so u lies
+ * strictly inside its stratum; larger designs are refused rather than rounded onto a stratum edge.
  * Host twin (bit-identical): fiveeqscm_amd.params.lhs_rows. */
 int fiveeq_lhs_rows_f64(uint64_t seed, int64_t n_total, int64_t m0, int64_t n_members,
                         int32_t dim0, int32_t n_dim, int64_t ld, double *out, void *stream);

@@ -188,3 +188,33 @@ def test_new_entry_points_validate_on_the_host():
     assert lib.fiveeq_hist_rows_chunks(0, 100) == 0 and lib.fiveeq_hist_rows_chunks(1, 100) == 1
     assert lib.fiveeq_hist_rows_chunks(1, 12_500_000) == 12_500_000 // 16384 + 1          # >= 16384 members per workgroup
     assert lib.fiveeq_hist_rows_chunks(750, 12_500_000) == 3                              # ~2048 workgroups over all rows
+
+
+def test_abi_v5_host_side_guards():
+    """ABI v5: the tile size comes from the device's LDS attribute (the gfx950 figure without a device), the tiled
+    kernel's dynamic-LDS limit is set once per instantiation (never here: nothing is launched), K-step spans are clamped
+    to the step range before any loop arithmetic, and Latin-hypercube designs stop at 2^28 members, where stratum +
+    jitter is still an exact fp64 sum."""
+    import numpy as np
+    lib = _capi.load()
+    assert lib.fiveeq_tile_lds_bytes() == 160 * 1024 and lib.fiveeq_tile_attr_calls() == 0
+    m = prm.make_model(prm.default_params("multigas"))
+    p = ctypes.c_void_p(0x1000)
+    empty = (ctypes.byref(m), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, None)       # t_begin == t_end: nothing to launch
+    assert lib.fiveeq_run_ksteps_f64(*empty, 2**31 - 1, None) == _capi.OK
+    assert lib.fiveeq_run_ksteps_f32(*empty, 1, None) == _capi.OK
+    out = np.empty((1, 4))
+    host = lambda n_total: lib.fiveeq_lhs_rows_host_f64(1, n_total, 0, 4, 0, 1, 4, out.ctypes.data_as(ctypes.c_void_p))  # noqa: E731
+    assert host(1 << 28) == _capi.OK and np.all((out > 0) & (out < 1))
+    assert host((1 << 28) + 1) == _capi.E_INVALID and b"2^28" in lib.fiveeq_last_error()
+    assert lib.fiveeq_lhs_rows_f64(1, 1 << 40, 0, 4, 0, 1, 4, p, None) == _capi.E_INVALID
+    with pytest.raises(ValueError, match="2\\^28"):
+        prm.lhs_rows((1 << 28) + 1, [0], 0, 4)
+    # at the cap the twins still agree bit for bit and every u sits strictly inside its stratum
+    n = 1 << 28
+    u = prm.lhs_rows(n, [0, 1], n - 1000, n)
+    got = np.empty_like(u)
+    assert lib.fiveeq_lhs_rows_host_f64(prm.LHS_SEED, n, n - 1000, 1000, 0, 2, 1000, got.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(u, got)
+    scaled = u * n
+    assert np.all(scaled - np.floor(scaled) > 0) and np.all(np.floor(scaled) < n)

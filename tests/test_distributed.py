@@ -195,3 +195,54 @@ def test_gloo_world8_config4_rehearsal_against_the_oracle():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert all(results)
+
+
+def test_forced_collectives_in_a_one_rank_group():
+    """force_collectives: in a process group of ONE rank every collective of the summary exchange executes on the
+    backend instead of being skipped — here over gloo; tests/test_distributed_gpu.py runs the same over RCCL on one
+    GPU.  Results must equal the no-process-group answers."""
+    import torch.distributed as dist
+
+    from fiveeqscm_amd import distributed as D
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rng = np.random.default_rng(5)
+    rows = torch.from_numpy(rng.normal(1.5, 0.7, size=(3, 40_001)))
+    sums = torch.stack([torch.full((3,), 40_001.0, dtype=torch.float64), rows.sum(1), (rows * rows).sum(1),
+                        rows.min(1).values, rows.max(1).values], dim=1)
+    hist = torch.from_numpy(_np_hist(rows.numpy(), -2.0, 5.0, 512))
+    want = gather_summary(rows, percentiles=(5.0, 50.0, 95.0))
+    want_m, want_h = reduce_stats(sums), histogram_percentiles(hist, -2.0, 5.0)
+    calls = []
+    real = {name: getattr(dist, name) for name in ("all_reduce", "all_gather", "gather")}
+
+    def spy(name):
+        def f(*a, **k):
+            calls.append(name)
+            return real[name](*a, **k)
+        return f
+
+    dist.init_process_group("gloo", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}")
+    prev = D.force_collectives(True)
+    try:
+        for name in real:
+            setattr(dist, name, spy(name))
+        st = {}
+        got = gather_summary(rows, percentiles=(5.0, 50.0, 95.0), stats=st)
+        got_m, got_h = reduce_stats(sums), histogram_percentiles(hist, -2.0, 5.0)
+    finally:
+        for name, fn in real.items():
+            setattr(dist, name, fn)
+        D.force_collectives(prev)
+        dist.destroy_process_group()
+    # moments all_gather; histogram + below-counts all_reduce; sizes all_gather; candidates gather; 3 + 1 all_reduces
+    assert calls.count("all_gather") == 2 and calls.count("gather") == 1 and calls.count("all_reduce") == 2 + 3 + 1
+    np.testing.assert_allclose(got["percentiles"].numpy(), np.percentile(rows.numpy(), (5.0, 50.0, 95.0), axis=1).T,
+                               rtol=1e-13)
+    np.testing.assert_allclose(got["percentiles"].numpy(), want["percentiles"].numpy(), rtol=1e-13)
+    assert st["bytes_to_root"] == 0 and st["allreduce_bytes"] > 0
+    for k in ("mean", "var", "min", "max", "count"):
+        assert torch.equal(got_m[k], want_m[k])
+        np.testing.assert_allclose(got[k].numpy(), want[k].numpy(), rtol=1e-12)
+    assert torch.equal(got_h[0], want_h[0]) and torch.equal(got_h[1], want_h[1])

@@ -7,6 +7,9 @@
     ORACLE's T over the whole ensemble, plus the engine's own single-process results bit for bit.
 (2) The same exchange over RCCL ("nccl"), one rank per GPU: skips itself on a box with fewer than two GPUs, so the
     first multi-GPU lease exercises dist.gather / all_reduce over xGMI in a test rather than in bench.py.
+(3) RCCL first contact on ONE GPU: a "nccl" process group of one rank with distributed.force_collectives, so every
+    collective the summary makes (all_gather fp64, all_reduce SUM int64 [750, 4096], MIN / MAX fp64, gather of a device
+    tensor with a receive list, barrier) executes on the device backend instead of being skipped by "one rank".
 """
 import os
 import socket
@@ -109,3 +112,87 @@ def test_summary_exchange_over_rccl():
     if n < 2:
         pytest.skip(f"{n} GPU(s) visible: the RCCL leg needs at least 2")
     _launch(min(n, 4), "nccl")
+
+
+def _first_contact_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from fiveeqscm_amd import distributed as D
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # "nccl" is RCCL on ROCm
+    calls = []
+    real = {name: getattr(dist, name) for name in ("all_reduce", "all_gather", "gather", "barrier")}
+
+    def spy(name):
+        def f(*a, **k):
+            t = a[0] if a and isinstance(a[0], torch.Tensor) else None
+            calls.append((name, None if t is None else (str(t.dtype), t.is_cuda)))
+            return real[name](*a, **k)
+        return f
+
+    try:
+        assert dist.get_backend() == "nccl"
+        D.force_collectives(True)
+        for name in real:
+            setattr(dist, name, spy(name))
+        g = torch.Generator(device=dev).manual_seed(7)
+        rows = torch.randn((3, 300_001), generator=g, device=dev, dtype=torch.float64) * 0.6 + 1.8
+        rows32 = rows.to(torch.float32)
+        st = {}
+        summ = D.gather_summary(rows, percentiles=PCT, stats=st)
+        summ32 = D.gather_summary(rows32, percentiles=PCT)
+        hist = torch.randint(0, 1000, (750, 4096), generator=g, device=dev, dtype=torch.int64)
+        hp, tot = D.histogram_percentiles(hist, -1.0, 6.0, PCT)
+        sums = torch.stack([torch.full((3,), float(rows.shape[1]), dtype=torch.float64, device=dev), rows.sum(1),
+                            (rows * rows).sum(1), rows.min(1).values, rows.max(1).values], dim=1)
+        mom = D.reduce_stats(sums)
+        el = torch.tensor([1.25, 0.5], dtype=torch.float64, device=dev)       # bench.py's max-over-ranks of the block times
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize()
+        x = rows.cpu().numpy()
+        ok = {
+            "percentiles": np.allclose(summ["percentiles"].cpu().numpy(), np.percentile(x, PCT, axis=1).T, rtol=1e-13),
+            "percentiles_f32": np.allclose(summ32["percentiles"].cpu().numpy(),
+                                           np.percentile(rows32.cpu().numpy().astype(np.float64), PCT, axis=1).T, rtol=1e-13),
+            "mean": np.allclose(summ["mean"].cpu().numpy(), x.mean(1), rtol=1e-12),
+            "var": np.allclose(summ["var"].cpu().numpy(), x.var(1), rtol=1e-9),
+            "minmax": np.array_equal(mom["min"].cpu().numpy(), x.min(1)) and np.array_equal(mom["max"].cpu().numpy(), x.max(1)),
+            "hist_total": torch.equal(tot.cpu(), hist.sum(1).to(torch.float64).cpu()) and bool(torch.isfinite(hp).all()),
+            "elapsed_max": el.tolist() == [1.25, 0.5],
+            "payload": st["bytes_to_root"] == 0 and st["allreduce_bytes"] == 3 * 4096 * 8 + 3 * len(PCT) * 8,
+            # every collective ran on DEVICE tensors: nothing was staged through the host
+            "on_device": all(c[1] is None or c[1][1] for c in calls),
+            "calls": ({c[0] for c in calls} == {"all_reduce", "all_gather", "gather", "barrier"}
+                      and ("all_reduce", ("torch.int64", True)) in calls and ("gather", ("torch.float64", True)) in calls
+                      and ("gather", ("torch.float32", True)) in calls),
+        }
+        q.put({k: bool(v) for k, v in ok.items()})
+    except Exception as exc:  # noqa: BLE001 - report instead of leaving the parent waiting on the queue
+        q.put({f"{type(exc).__name__}: {exc}": False})
+        raise
+    finally:
+        for name, fn in real.items():
+            setattr(dist, name, fn)
+        dist.destroy_process_group()
+
+
+def test_rccl_first_contact_on_one_gpu():
+    """RCCL executes every call of the summary exchange on the one GPU of the test box (a one-rank "nccl" group with
+    force_collectives), in a child process so that the communicator's lifetime is that process's."""
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_first_contact_worker, args=(port, q))
+    p.start()
+    try:
+        res = q.get(timeout=600)
+    finally:
+        p.join(timeout=120)
+    assert p.exitcode == 0
+    assert all(res.values()), res

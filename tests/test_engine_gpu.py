@@ -308,7 +308,7 @@ def test_checkpoint_state_dict_roundtrip(gpu, tmp_path):
     whole.run(mode="tiled")
     first = _engine(p, N, E, **kw)
     first.run(0, 33, mode="tiled")
-    ck = first.state_dict()
+    ck = first.state_dict(include_outputs=True)
     assert ck["t_next"] == 33
     np.savez(tmp_path / "ck.npz", **ck)
     second = _engine(p, N, E, **kw)
@@ -320,6 +320,19 @@ def test_checkpoint_state_dict_roundtrip(gpu, tmp_path):
     # the checkpoint carries what the run had accumulated: ALL rows, moments and histograms equal an uninterrupted run
     assert torch.equal(second.T, whole.T) and torch.equal(second.C, whole.C)
     assert torch.equal(second.T_stats, whole.T_stats) and torch.equal(second.T_hist, whole.T_hist)
+    # the default checkpoint carries the REDUCED outputs only (histograms + folded per-step moments; no per-wave records,
+    # no stored rows): small whatever the ensemble size, and the resumed run's summaries still equal the uninterrupted run's
+    small = first.state_dict()
+    assert set(small) == {"R", "S", "t_next", "T_hist", "_step_sums", "_step_sums_valid"}
+    assert small["_step_sums"].shape == (n_steps, 5) and small["_step_sums_valid"].tolist() == [True] * 33 + [False] * 57
+    third = _engine(p, N, E, **kw)
+    third.load_state_dict(small)
+    third.run(33, n_steps, mode="tiled", k_steps=5)                      # another launch shape after the resume
+    torch.cuda.synchronize()
+    assert torch.equal(third.T_hist, whole.T_hist) and torch.equal(third.T[33:], whole.T[33:])
+    assert int(third.T[:33].abs().sum()) == 0                            # rows of the first leg were not carried
+    a, b = third.stats_sums(), whole.stats_sums()
+    assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]) and torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-13, atol=0)
     bare = _engine(p, N, E)
     bare.load_state_dict(first.state_dict(include_outputs=False))      # state only: later rows still right
     bare.run(33, n_steps, mode="fused")
@@ -327,6 +340,45 @@ def test_checkpoint_state_dict_roundtrip(gpu, tmp_path):
     assert torch.equal(bare.T[33:], whole.T[33:]) and torch.equal(bare.C[33:], whole.C[33:])
     with pytest.raises(ValueError):
         second.load_state_dict({"R": np.zeros((2, 2)), "S": np.zeros((2, N))})
+
+
+def test_reset_and_reload_clear_the_run_accumulators(gpu):
+    """T_hist accumulates and the streamed pipeline leaves per-step moments behind: reset_state() and a state-only
+    load_state_dict() must clear both, or a second run double-counts its histogram and reads the first run's moments."""
+    N, n_steps = 3000, 40
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(750, 3)[240:240 + n_steps]
+    eng = _engine(p, N, E, store_concentrations=False, collect_stats=True, hist=(-1.0, 4.0, 256), hist_ring_steps=8)
+    eng.run(mode="fused")                                                # streamed: moments come from the histogram pass
+    torch.cuda.synchronize()
+    hist1, sums1 = eng.T_hist.clone(), eng.stats_sums().clone()
+    assert eng._step_sums_valid.all() and hist1.sum(1).tolist() == [N] * n_steps
+    eng.reset_state()
+    assert int(eng.T_hist.sum()) == 0 and not eng._step_sums_valid.any()
+    eng.run(mode="fused")
+    torch.cuda.synchronize()
+    assert torch.equal(eng.T_hist, hist1) and torch.equal(eng.stats_sums(), sums1)       # not doubled
+    # another state, another mode: wave records are written and must be what stats_sums() reads
+    other = _engine(p, N, E * 1.7, store_concentrations=False, collect_stats=True)
+    other.run(0, 11, mode="fused")
+    eng.load_state_dict(other.state_dict(include_outputs=False))
+    assert int(eng.T_hist.sum()) == 0 and not eng._step_sums_valid.any() and eng.t_next == 11
+    eng.run(11, n_steps, mode="tiled")
+    torch.cuda.synchronize()
+    want = _engine(p, N, E, store_concentrations=False, collect_stats=True)
+    want.load_state_dict(other.state_dict(include_outputs=False))
+    want.run(11, n_steps, mode="per_step")
+    torch.cuda.synchronize()
+    a, b = eng.stats_sums(11, n_steps), want.stats_sums(11, n_steps)
+    assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]) and torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-13, atol=0)
+    assert not torch.allclose(a[:, 1], sums1[11:, 1], rtol=1e-6)                        # and NOT the first run's moments
+    # a run that overwrites streamed steps with wave-record steps invalidates the pass moments of exactly those steps
+    eng.reset_state()
+    eng.run(mode="fused")
+    eng.run(16, 24, mode="tiled")
+    assert eng._step_sums_valid[:16].all() and not eng._step_sums_valid[16:24].any() and eng._step_sums_valid[24:].all()
+    for e in (eng, other, want):
+        e.close()
 
 
 def test_all_compiled_layouts_match_oracle(gpu):
@@ -1065,3 +1117,31 @@ def test_percentile_selection_on_device_rows(gpu, dtype):
     np.testing.assert_allclose(got.cpu().numpy(), np.percentile(xs, pct, axis=1).T, rtol=1e-13, atol=0)
     one = gather_summary(xt, percentiles=pct)                   # one rank: the sort path
     np.testing.assert_allclose(one["percentiles"].cpu().numpy(), np.percentile(xs, pct, axis=1).T, rtol=1e-13, atol=0)
+
+
+def test_tiled_kernel_lds_limit_is_set_once_per_instantiation(gpu):
+    """The tiled kernel's dynamic-LDS limit is a property of (kernel instantiation, device): it is raised once, to what
+    the device allows, and not per launch; the LDS size itself is read from the device (160 KiB on MI355X)."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    assert lib.fiveeq_tile_lds_bytes() == 160 * 1024
+    assert lib.fiveeq_tile_steps_f64(4096) == 11 and lib.fiveeq_tile_steps_f32(4096) == 15
+    N, n_steps = 2000, 66
+    E = emi.rcp_like_emissions(750, 3)[250:250 + n_steps]
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    counts = []
+    for layout_case in range(2):
+        for rep in range(3):
+            eng = _engine(p, N, E, dtype=(torch.float64, torch.float32)[layout_case], store_trajectory=False,
+                          hist=(-1.0, 5.0, 4096))
+            eng.run(mode="tiled")                          # 6 launches of 11 (fp64) / 5 of 15 (fp32) steps, 88 / 120 KiB of LDS each
+            torch.cuda.synchronize()
+            assert eng.T_hist.sum(1).tolist() == [N] * n_steps
+            counts.append(lib.fiveeq_tile_attr_calls())
+            eng.close()
+    assert counts[0] == counts[1] == counts[2] and counts[3] == counts[4] == counts[5] == counts[0] + 1
+    small = _engine(p, N, E, store_trajectory=False, hist=(-1.0, 5.0, 512))
+    small.run(mode="tiled")                                # 32 x 1 KiB: under 48 KiB, no attribute needed
+    torch.cuda.synchronize()
+    assert lib.fiveeq_tile_attr_calls() == counts[-1]
+    small.close()

@@ -36,7 +36,6 @@ eng.run(mode=MODE)                                   # first pass: allocates the
 torch.cuda.synchronize()
 t3 = time.perf_counter()
 eng.reset_state()
-eng.T_hist.zero_()
 torch.cuda.synchronize()
 t3a = time.perf_counter()
 eng.run(mode=MODE)                                   # steady state

@@ -20,8 +20,6 @@ def timed(eng, reps=3):
     best = None
     for _ in range(reps + 1):
         eng.reset_state()
-        if eng.T_hist is not None:
-            eng.T_hist.zero_()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.run(mode="fused")

@@ -20,7 +20,8 @@ p = params.sample_ensemble_shard(params.default_params(kind), N, device="cuda:0"
 E = emissions.rcp_like_emissions(750, 3 if kind == "multigas" else 1)[250:250 + STEPS]
 eng = EnsembleEngine(p, N, E, dtype=dt, device="cuda:0", store_trajectory=False, collect_stats=True,
                      hist=(-2.0, 12.0, 4096))
-for _ in range(2):
+eng._wave_stats()            # the raw C entry below bypasses run(): allocate the wave records first, so that the fused
+for _ in range(2):           # counters include the in-kernel statistics exactly like the tiled ones do
     eng.reset_state()
     fn = getattr(eng.lib, f"fiveeq_run_fused_{eng._sfx}")          # the plain fused kernel (no histogram pipeline)
     assert fn(*eng._run_args(0, STEPS), eng._stream()) == 0

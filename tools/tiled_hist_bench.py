@@ -22,8 +22,6 @@ def timed(eng, reps, **kw):
     best = None
     for _ in range(reps + 1):                      # first pass warms clocks / code objects
         eng.reset_state()
-        if eng.T_hist is not None:
-            eng.T_hist.zero_()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.run(**kw)
