@@ -90,6 +90,7 @@ SIGNATURES = {
     "fiveeq_run_tiled_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
     "fiveeq_tile_steps_f64": (_i32, [_i32]),
     "fiveeq_tile_steps_f32": (_i32, [_i32]),
+    "fiveeq_set_f32_packing": (ctypes.c_int, [ctypes.c_int]),
     "fiveeq_tile_lds_bytes": (_i32, []),
     "fiveeq_tile_attr_calls": (_i32, []),
     "fiveeq_lhs_rows_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p, _p]),

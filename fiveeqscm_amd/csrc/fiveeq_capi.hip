@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #ifndef FIVEEQ_FUSED_DYN_LDS
 #define FIVEEQ_FUSED_DYN_LDS 0     // experiment knob: unused dynamic LDS per fused workgroup, to cap occupancy
@@ -148,16 +149,46 @@ struct RunArgs {
     double* stats;
 };
 
+// ---- packed fp32 lanes: two members per lane (fiveeq_device.hpp, "Lane value types") ----------------------------
+// The fp32 entry points run the packed kernels whenever the rows allow 8-byte accesses: even row stride, every row
+// pointer 8-byte aligned, at least two members.  Otherwise (odd ld, a sub-range starting at an odd member) the
+// one-member-per-lane kernels run; both give the same bits.  fiveeq_set_f32_packing(0) forces the scalar kernels (A/B
+// measurements, and the tests that compare the two).
+int g_f32_packing = 1;
+
+template <typename T>
+struct LaneOf {
+    using Packed = T;                              // fp64 has no packed VALU forms: one member per lane
+    static bool can_pack(const RunArgs<T>&) { return false; }
+};
+template <>
+struct LaneOf<float> {
+    using Packed = float2v;
+    static bool can_pack(const RunArgs<float>& a) {
+        if (!g_f32_packing || a.n < 2 || (a.ld & 1)) return false;
+        const uintptr_t bits = (uintptr_t)a.r | (uintptr_t)a.q | (uintptr_t)a.R | (uintptr_t)a.S | (uintptr_t)a.C_traj |
+                               (uintptr_t)a.T_traj;
+        return (bits & 7u) == 0;
+    }
+};
+
 template <typename T>
 int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
-    const int64_t blocks = (a.n + FIVEEQ_STEP_BLOCK - 1) / FIVEEQ_STEP_BLOCK;
+    using P = typename LaneOf<T>::Packed;
+    const bool packed = LaneOf<T>::can_pack(a);
+    const int64_t per_block = (int64_t)FIVEEQ_STEP_BLOCK * (packed ? 2 : 1);
+    const int64_t blocks = (a.n + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_STEP_BLOCK);
     switch (a.code) {
 #define X(p0, p1, p2)                                                                             \
     case (p0) * 100 + (p1) * 10 + (p2):                                                           \
-        hipLaunchKernelGGL((step_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
-                           a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);                \
+        if (packed)                                                                               \
+            hipLaunchKernelGGL((step_kernel<P, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
+                               a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);            \
+        else                                                                                      \
+            hipLaunchKernelGGL((step_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
+                               a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);            \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X
@@ -170,12 +201,23 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
 
 template <typename T, bool INV>
 int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream_t st) {
-    const int64_t blocks = member_blocks(a.n);
+    using P = typename LaneOf<T>::Packed;
+    constexpr bool HAS_PACKED = !INV && !std::is_same<P, T>::value;     // the inverse form has no packed instantiation
+    const bool packed = HAS_PACKED && LaneOf<T>::can_pack(a);
+    const int64_t blocks = member_blocks(packed ? (a.n + 1) / 2 : a.n);
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_BLOCK);
     switch (a.code) {
 #define X(p0, p1, p2)                                                                                  \
     case (p0) * 100 + (p1) * 10 + (p2):                                                                \
+        if constexpr (HAS_PACKED) {                                                                    \
+            if (packed) {                                                                              \
+                hipLaunchKernelGGL((fused_kernel<P, p0, p1, p2, false>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km, a.drive, \
+                                   a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj, a.T_traj,      \
+                                   a.n_rows, a.stats);                                                 \
+                break;                                                                                 \
+            }                                                                                          \
+        }                                                                                              \
         hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km, a.drive, a.n_steps, t_begin, \
                            t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj, a.T_traj, a.n_rows,   \
                            a.stats);                                                                   \
@@ -539,6 +581,11 @@ int fiveeq_run_tiled_f32(const fiveeq_model* model, int64_t n_members, int64_t l
     return run_tiled<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
                             T_stats, k_steps, hist_lo, hist_hi, n_bins, T_hist, stream);
 }
+int fiveeq_set_f32_packing(int on) {
+    const int prev = g_f32_packing;
+    g_f32_packing = on ? 1 : 0;
+    return prev;
+}
 int32_t fiveeq_tile_lds_bytes(void) { return device_lds_bytes(); }
 int32_t fiveeq_tile_attr_calls(void) { return g_tile_attr_calls; }
 int32_t fiveeq_tile_steps_f64(int32_t n_bins) { return n_bins < 0 || n_bins > fiveeq::HIST_MAX_BINS ? 0 : tile_steps_max<double>(n_bins); }
@@ -682,8 +729,10 @@ int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, d
 
 template <typename T>
 int math_probe(int32_t op, int64_t n, const T* x, T* y, void* stream) {
-    if (op < 0 || op > 4) return fail(FIVEEQ_E_INVALID, "op=%d outside 0..4", op);
+    const bool packed_op = sizeof(T) == 4 && op >= 8 && op <= 12;          // fp32: the packed twin on element pairs
+    if ((op < 0 || op > 4) && !packed_op) return fail(FIVEEQ_E_INVALID, "op=%d outside 0..4 (fp32: also 8..12)", op);
     if (n < 1) return fail(FIVEEQ_E_INVALID, "n=%lld must be >= 1", (long long)n);
+    if (packed_op && (n & 1)) return fail(FIVEEQ_E_INVALID, "packed ops need an even n");
     if (!x || !y) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
     const int64_t blocks = member_blocks(n);
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n too large");

@@ -68,6 +68,37 @@ struct KModel {
 __device__ __forceinline__ double fe_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fe_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// ---------------------------------------------------------------------------------
+// Lane value types.  A lane carries ONE member (V = double or float) or, in the packed fp32 kernels, TWO CONSECUTIVE
+// members (V = float2v: lane l of a wave owns members 2l and 2l + 1 of the wave's 128).  Packed lanes load and store
+// 8 bytes per row (512 B per wave-instruction, the fp64 kernels' access shape) and their multiplies, adds and FMAs issue
+// as v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 — one instruction for both members (5.0-5.2 cycles per wave-instruction
+// against 2 x 2.9-3.6 for the scalar forms, profiles/r03/valu_rates_microbench.txt); what the ISA has no packed form
+// for (v_rcp_f32, v_sqrt_f32, v_rndne_f32, v_ldexp_f32, v_frexp_*, min/max, compares and selects) runs per component.
+// Packed arithmetic is IEEE per component and every routine below mirrors its scalar twin operation by operation, so a
+// member's result does not depend on which kernel shape computed it (tested bit for bit).
+// ---------------------------------------------------------------------------------
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <typename V> struct Lane { using S = V; static constexpr int W = 1; };
+template <> struct Lane<float2v> { using S = float; static constexpr int W = 2; };
+
+__device__ __forceinline__ float2v fe_fma(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+// fma with any mix of lane values and shared scalars (constants are splat into both components)
+template <typename V, typename A, typename B, typename C>
+__device__ __forceinline__ V fma3(A a, B b, C c) { return fe_fma((V)a, (V)b, (V)c); }
+
+// per-lane predicates and selects
+struct Mask2 { bool x, y; };
+template <typename V> struct MaskOf { using type = bool; };
+template <> struct MaskOf<float2v> { using type = Mask2; };
+__device__ __forceinline__ bool fe_gt0(double v) { return v > 0.0; }
+__device__ __forceinline__ bool fe_gt0(float v) { return v > 0.0f; }
+__device__ __forceinline__ Mask2 fe_gt0(float2v v) { return Mask2{v.x > 0.0f, v.y > 0.0f}; }
+__device__ __forceinline__ double fe_sel(bool m, double a, double b) { return m ? a : b; }
+__device__ __forceinline__ float fe_sel(bool m, float a, float b) { return m ? a : b; }
+__device__ __forceinline__ float2v fe_sel(Mask2 m, float2v a, float2v b) { return float2v{m.x ? a.x : b.x, m.y ? a.y : b.y}; }
+
 template <int P0, int P1, int P2>
 struct Layout {
     static constexpr int G = (P0 > 0) + (P1 > 0) + (P2 > 0);
@@ -118,28 +149,46 @@ __device__ __forceinline__ double fe_expm1_neg(double x) {
     const double s = __builtin_ldexp(1.0, (int)k);           // 2^k, k <= 0
     return __builtin_fma(s, p, s - 1.0);                     // k = 0: exactly p
 }
-// fp32 twins of the routines above (same structure, float constants): Cody-Waite ln2 split with 12
-// zero low bits in the high part, degree-7 Taylor of expm1(r) (truncation 1.5e-8 relative).
+// fp32 routines.  Same scheme, re-cut for what the fp32 VALU is good at (round 3; each step measured on the fused
+// config-5 shard, profiles/r03/ab_variants.txt):
+//   * expm1(r) = r + r^2 Q(r) with Q the DEGREE-4 interpolant of (expm1(r) - r)/r^2 at the Chebyshev nodes of
+//     |r| <= ln2/2 (2.3e-8 relative — the degree-5 Taylor polynomial it replaces had 1.8e-8 — one FMA fewer per call);
+//   * the reduction x = k ln2 + r takes k from the magic-number add u = fma(x, log2 e, 1.5 * 2^23) (round to nearest even
+//     in the add itself), k = u - magic, and builds 2^k from u's low mantissa bits with one integer shift-add — no
+//     v_rndne / v_cvt / v_ldexp; the argument is clamped at -87 so that 2^k stays a normal float (expm1 is -1 below -17);
+//   * exp (the alpha closure) uses the hardware 2^t (v_exp_f32, 1 ulp) on t = x log2(e) with the product's rounding
+//     error and the low part of log2(e) folded back in: exp(x) = 2^t (1 + lo ln2), six instructions instead of fourteen.
+// All within 2 ulp(float) of libm over the model's ranges (tests/test_engine_gpu.py, through fiveeq_math_probe_f32).
 __device__ __forceinline__ float fe_expm1_reduced(float r) {
-    float q = 1.0f / 5040.0f;
-    q = __builtin_fmaf(q, r, 1.0f / 720.0f);
-    q = __builtin_fmaf(q, r, 1.0f / 120.0f);
-    q = __builtin_fmaf(q, r, 1.0f / 24.0f);
-    q = __builtin_fmaf(q, r, 1.0f / 6.0f);
+    float q = 0x1.6d10fcp-10f;
+    q = __builtin_fmaf(q, r, 0x1.120b62p-7f);
+    q = __builtin_fmaf(q, r, 0x1.55551ap-5f);
+    q = __builtin_fmaf(q, r, 0x1.5554dep-3f);
     q = __builtin_fmaf(q, r, 0.5f);
     return __builtin_fmaf(r * r, q, r);
 }
-__device__ __forceinline__ float fe_reduce_ln2(float x, float& k) {
-    k = __builtin_rintf(x * 1.44269504088896341f);
-    const float r = __builtin_fmaf(-k, 0.693145751953125f, x);
-    return __builtin_fmaf(-k, 1.42860682030941723212e-6f, r);
+constexpr float F32_LOG2E = 1.44269504088896341f;
+constexpr float F32_LN2_HI = 0.693145751953125f;             // 12 zero low bits: k * hi is exact
+constexpr float F32_LN2_LO = 1.42860682030941723212e-6f;
+constexpr float F32_RINT_MAGIC = 12582912.0f;                // 1.5 * 2^23
+// 2^k for the integer k held in the low mantissa bits of u = 1.5 * 2^23 + k, -126 <= k <= 0: (bits(u) << 23) + bits(1.0f),
+// one v_lshl_add_u32.  Written as inline asm: as plain C++ the packed form below was MISCOMPILED by hipcc 7.2 (the shift-add
+// of the second component was dropped and the first component's 2^k used for both members; found by the packed-vs-scalar
+// probe test).  Not volatile: the scheduler may still move it.
+__device__ __forceinline__ float fe_exp2_from_magic(float u) {
+    float s;
+    asm("v_lshl_add_u32 %0, %1, 23, 1.0" : "=v"(s) : "v"(u));
+    return s;
 }
 __device__ __forceinline__ float fe_expm1_neg(float x) {
-    x = fmaxf(x, -100.0f);                                   // expf(-100) == 0: result -1
-    float k;
-    const float p = fe_expm1_reduced(fe_reduce_ln2(x, k));
-    const float s = __builtin_ldexpf(1.0f, (int)k);
-    return __builtin_fmaf(s, p, s - 1.0f);
+    x = fmaxf(x, -87.0f);                                    // k >= -126
+    const float u = __builtin_fmaf(x, F32_LOG2E, F32_RINT_MAGIC);      // magic + rint(x log2 e)
+    const float k = u - F32_RINT_MAGIC;
+    float r = __builtin_fmaf(-k, F32_LN2_HI, x);
+    r = __builtin_fmaf(-k, F32_LN2_LO, r);
+    const float p = fe_expm1_reduced(r);
+    const float s = fe_exp2_from_magic(u);
+    return __builtin_fmaf(s, p, s - 1.0f);                   // k = 0: exactly p
 }
 
 // exp(x) for the alpha closure.  The argument is clamped to +-700 so that alpha is always a
@@ -150,11 +199,16 @@ __device__ __forceinline__ double fe_exp(double x) {
     const double p = fe_expm1_reduced(fe_reduce_ln2(x, k));
     return __builtin_ldexp(1.0 + p, (int)k);
 }
+constexpr float F32_LOG2E_HI = 0x1.715476p+0f;               // log2(e) rounded to float, and what it leaves
+constexpr float F32_LOG2E_LO = 0x1.4ae0cp-26f;
+constexpr float F32_LN2 = 0.693147182f;
 __device__ __forceinline__ float fe_exp(float x) {
     x = fminf(fmaxf(x, -80.0f), 80.0f);                      // alpha stays a finite normal float
-    float k;
-    const float p = fe_expm1_reduced(fe_reduce_ln2(x, k));
-    return __builtin_ldexpf(1.0f + p, (int)k);
+    const float t = x * F32_LOG2E_HI;
+    float lo = __builtin_fmaf(x, F32_LOG2E_HI, -t);          // the product's rounding error, exactly
+    lo = __builtin_fmaf(x, F32_LOG2E_LO, lo);
+    const float e = __builtin_amdgcn_exp2f(t);               // v_exp_f32
+    return __builtin_fmaf(e, lo * F32_LN2, e);
 }
 
 // 1/a for finite normal a > 0 (alpha): v_rcp_f64 seed + two Newton steps (<= 1 ulp), without the
@@ -239,6 +293,62 @@ __device__ __forceinline__ float fe_sqrt(float x) {
 __device__ __forceinline__ double fe_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ float fe_min(float a, float b) { return fminf(a, b); }
 
+// ---- packed fp32 twins (two members per lane): the same operations in the same order as the float routines above ----
+__device__ __forceinline__ float2v fe_min(float2v a, float b) { return float2v{fminf(a.x, b), fminf(a.y, b)}; }
+__device__ __forceinline__ float2v fe_expm1_reduced(float2v r) {
+    float2v q = (float2v)0x1.6d10fcp-10f;
+    q = fe_fma(q, r, (float2v)0x1.120b62p-7f);
+    q = fe_fma(q, r, (float2v)0x1.55551ap-5f);
+    q = fe_fma(q, r, (float2v)0x1.5554dep-3f);
+    q = fe_fma(q, r, (float2v)0.5f);
+    return fe_fma(r * r, q, r);
+}
+__device__ __forceinline__ float2v fe_expm1_neg(float2v x) {
+    x = float2v{fmaxf(x.x, -87.0f), fmaxf(x.y, -87.0f)};
+    const float2v u = fe_fma(x, (float2v)F32_LOG2E, (float2v)F32_RINT_MAGIC);
+    const float2v k = u - F32_RINT_MAGIC;
+    float2v r = fe_fma(-k, (float2v)F32_LN2_HI, x);
+    r = fe_fma(-k, (float2v)F32_LN2_LO, r);
+    const float2v p = fe_expm1_reduced(r);
+    const float2v s = float2v{fe_exp2_from_magic(u.x), fe_exp2_from_magic(u.y)};
+    return fe_fma(s, p, s - 1.0f);
+}
+__device__ __forceinline__ float2v fe_exp(float2v x) {
+    x = float2v{fminf(fmaxf(x.x, -80.0f), 80.0f), fminf(fmaxf(x.y, -80.0f), 80.0f)};
+    const float2v t = x * F32_LOG2E_HI;
+    float2v lo = fe_fma(x, (float2v)F32_LOG2E_HI, -t);
+    lo = fe_fma(x, (float2v)F32_LOG2E_LO, lo);
+    const float2v e = float2v{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    return fe_fma(e, lo * F32_LN2, e);
+}
+__device__ __forceinline__ float2v fe_rcp(float2v a) {
+    const float2v y = float2v{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+    return fe_fma(y, fe_fma(-a, y, (float2v)1.0f), y);
+}
+__device__ __forceinline__ float2v fe_log(float2v x) {
+    float mx = __builtin_amdgcn_frexp_mantf(x.x), my = __builtin_amdgcn_frexp_mantf(x.y);
+    int kx = __builtin_amdgcn_frexp_expf(x.x), ky = __builtin_amdgcn_frexp_expf(x.y);
+    const bool lowx = mx < 0.70710678118654752440f, lowy = my < 0.70710678118654752440f;
+    mx = lowx ? mx + mx : mx;
+    my = lowy ? my + my : my;
+    kx = lowx ? kx - 1 : kx;
+    ky = lowy ? ky - 1 : ky;
+    const float2v dk = float2v{(float)kx, (float)ky};
+    const float2v f = float2v{mx, my} - 1.0f;
+    const float2v s = f * fe_rcp(2.0f + f);
+    const float2v z = s * s;
+    const float2v w = z * z;
+    const float2v t1 = w * fe_fma(w, (float2v)0.24279078841f, (float2v)0.40000972152f);
+    const float2v t2 = z * fe_fma(w, (float2v)0.28498786688f, (float2v)0.66666662693f);
+    const float2v R = t2 + t1;
+    const float2v hfsq = 0.5f * f * f;
+    const float2v tail = fe_fma(dk, (float2v)9.0580006145e-06f, s * (hfsq + R));
+    return fe_fma(dk, (float2v)6.9313812256e-01f, -((hfsq - tail) - f));
+}
+__device__ __forceinline__ float2v fe_sqrt(float2v x) {
+    return float2v{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+}
+
 // ---------------------------------------------------------------------------------
 // One member, one step.  All state lives in registers; the caller moves it.
 //   drv : this step's drive record (LDS): [0..2] E_g, [3..5] cumE_g, [6] F_ext
@@ -252,29 +362,35 @@ __device__ __forceinline__ float fe_min(float a, float b) { return fminf(a, b); 
 //     C* - C0 = sum_i R_i (1 + em1_i) - E alpha sum_i (a_i tau_i c) em1_i
 // and returned in out[g]; the pools are then advanced with that E.
 // ---------------------------------------------------------------------------------
-template <typename T, typename L, int g, bool INV>
-__device__ __forceinline__ T gas_step(const KModel<T>& km, const KGas<T>& kg, const T* __restrict__ drv,
-                                      const T (&rr)[3 * L::G], const T T_old, T (&R)[L::SP], T (&out)[L::G],
-                                      T (&cum)[L::G]) {
+// V is the lane value type (double, float, or float2v = two members per lane); S its scalar type: the shared model and
+// the drive record are S, everything per member is V.
+template <typename V, typename L, int g, bool INV>
+__device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, const KGas<typename Lane<V>::S>& kg,
+                                      const typename Lane<V>::S* __restrict__ drv, const V (&rr)[3 * L::G], const V T_old,
+                                      V (&R)[L::SP], V (&out)[L::G], V (&cum)[L::G]) {
+    using S = typename Lane<V>::S;
+    static_assert(!INV || Lane<V>::W == 1, "the concentration-driven form has no packed instantiation");
     constexpr int P = L::pools(g);
     constexpr int o = L::off(g);
     // --- alpha_val -----------------------------------------------------------------
-    T sumR = R[o];
+    V sumR = R[o];
 #pragma unroll
     for (int i = 1; i < P; ++i) sumR += R[o + i];
-    const T G_a = sumR * kg.inv_c;
-    const T G_u = (INV ? cum[g] : drv[3 + g]) - G_a;
-    T iirf = fe_fma(kg.ra, G_a, fe_fma(rr[3 * g + 2], T_old, fe_fma(rr[3 * g + 1], G_u, rr[3 * g])));
+    const V G_a = sumR * kg.inv_c;
+    V G_u;
+    if constexpr (INV) G_u = cum[g] - G_a;
+    else G_u = drv[3 + g] - G_a;
+    V iirf = fma3<V>(kg.ra, G_a, fma3<V>(rr[3 * g + 2], T_old, fma3<V>(rr[3 * g + 1], G_u, rr[3 * g])));
     iirf = fe_min(iirf, km.iirf_max);
-    const T alpha = kg.g0 * fe_exp(iirf * kg.inv_g1);
-    const T inv_alpha = fe_rcp(alpha);
+    const V alpha = kg.g0 * fe_exp(iirf * kg.inv_g1);
+    const V inv_alpha = fe_rcp(alpha);
     // --- step_conc -----------------------------------------------------------------
-    T em1[P];
+    V em1[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) em1[i] = fe_expm1_neg(kg.ndt_over_tau[i] * inv_alpha);
-    T E;
+    V E;
     if constexpr (INV) {
-        T num = T(0), den = T(0);
+        V num = V(0), den = V(0);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             num += fe_fma(R[o + i], em1[i], R[o + i]);
@@ -284,57 +400,62 @@ __device__ __forceinline__ T gas_step(const KModel<T>& km, const KGas<T>& kg, co
         cum[g] = fe_fma(E, km.dt, cum[g]);
         out[g] = E;
     } else {
-        E = drv[g];
+        E = (V)drv[g];
     }
-    const T Ea = E * alpha;
-    T sumN = T(0);
+    const V Ea = E * alpha;
+    V sumN = (V)S(0);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const T Ri = R[o + i];
-        const T Rn = fe_fma(em1[i], fe_fma(-kg.atc[i], Ea, Ri), Ri);     // R + em1 (R - a tau c E alpha)
+        const V Ri = R[o + i];
+        const V Rn = fe_fma(em1[i], fma3<V>(-kg.atc[i], Ea, Ri), Ri);     // R + em1 (R - a tau c E alpha)
         R[o + i] = Rn;
         sumN += Rn;
     }
-    const T Cg = kg.C0 + sumN;
+    const V Cg = kg.C0 + sumN;
     if constexpr (!INV) out[g] = Cg;
     // --- step_forc (terms whose coefficient is zero are skipped: wave-uniform branch) ---
-    const bool pos = Cg > T(0);
-    T Fg = kg.f2 * (Cg - kg.C0);
-    if (kg.f1 != T(0)) Fg = pos ? fe_fma(kg.f1, fe_log(pos ? Cg * kg.inv_C0 : T(1)), Fg) : Fg;
-    if (kg.f3 != T(0)) Fg = fe_fma(kg.f3, (pos ? fe_sqrt(pos ? Cg : T(1)) : T(0)) - kg.sqrtC0, Fg);
+    const auto pos = fe_gt0(Cg);
+    V Fg = kg.f2 * (Cg - kg.C0);
+    if constexpr (Lane<V>::W == 1) {
+        if (kg.f1 != S(0)) Fg = pos ? fe_fma(kg.f1, fe_log(pos ? Cg * kg.inv_C0 : S(1)), Fg) : Fg;
+        if (kg.f3 != S(0)) Fg = fe_fma(kg.f3, (pos ? fe_sqrt(pos ? Cg : S(1)) : S(0)) - kg.sqrtC0, Fg);
+    } else {
+        if (kg.f1 != S(0)) Fg = fe_sel(pos, fma3<V>(kg.f1, fe_log(fe_sel(pos, Cg * kg.inv_C0, (V)S(1))), Fg), Fg);
+        if (kg.f3 != S(0)) Fg = fma3<V>(kg.f3, fe_sel(pos, fe_sqrt(fe_sel(pos, Cg, (V)S(1))), (V)S(0)) - kg.sqrtC0, Fg);
+    }
     return Fg;
 }
 
-template <typename T, typename L, bool INV = false>
-__device__ __forceinline__ void member_step(const KModel<T>& km, const T* __restrict__ drv,
-                                            const T (&rr)[3 * L::G], const T (&qq)[2],
-                                            T (&R)[L::SP], T (&S)[2], T (&out)[L::G], T& Tnew, T (&cum)[L::G]) {
-    const T T_old = S[0] + S[1];
-    T F = drv[6];
+template <typename V, typename L, bool INV = false>
+__device__ __forceinline__ void member_step(const KModel<typename Lane<V>::S>& km, const typename Lane<V>::S* __restrict__ drv,
+                                            const V (&rr)[3 * L::G], const V (&qq)[2],
+                                            V (&R)[L::SP], V (&S)[2], V (&out)[L::G], V& Tnew, V (&cum)[L::G]) {
+    const V T_old = S[0] + S[1];
+    V F = (V)drv[6];
     // compiler-only barriers: keep each gas's LDS constant reads inside that gas's code instead of all
     // ~45 being hoisted to the kernel top (VGPR pressure) or out of the fused time loop.  (Issuing gas
     // g+1's reads before gas g's arithmetic was tried: +-1 %, 133 VGPRs; not kept.)
     asm volatile("" ::: "memory");
-    F += gas_step<T, L, 0, INV>(km, km.gas[0], drv, rr, T_old, R, out, cum);
+    F += gas_step<V, L, 0, INV>(km, km.gas[0], drv, rr, T_old, R, out, cum);
     if constexpr (L::G > 1) {
         asm volatile("" ::: "memory");
-        F += gas_step<T, L, 1, INV>(km, km.gas[1], drv, rr, T_old, R, out, cum);
+        F += gas_step<V, L, 1, INV>(km, km.gas[1], drv, rr, T_old, R, out, cum);
     }
     if constexpr (L::G > 2) {
         asm volatile("" ::: "memory");
-        F += gas_step<T, L, 2, INV>(km, km.gas[2], drv, rr, T_old, R, out, cum);
+        F += gas_step<V, L, 2, INV>(km, km.gas[2], drv, rr, T_old, R, out, cum);
     }
     // --- step_temp: S + em1_d (S - q F) ------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < 2; ++j) S[j] = fe_fma(km.em1_d[j], fe_fma(-qq[j], F, S[j]), S[j]);
+    for (int j = 0; j < 2; ++j) S[j] = fma3<V>(km.em1_d[j], fe_fma(-qq[j], F, S[j]), S[j]);
     Tnew = S[0] + S[1];
 }
-template <typename T, typename L>
-__device__ __forceinline__ void member_step(const KModel<T>& km, const T* __restrict__ drv,
-                                            const T (&rr)[3 * L::G], const T (&qq)[2],
-                                            T (&R)[L::SP], T (&S)[2], T (&C)[L::G], T& Tnew) {
-    T unused[L::G];
-    member_step<T, L, false>(km, drv, rr, qq, R, S, C, Tnew, unused);
+template <typename V, typename L>
+__device__ __forceinline__ void member_step(const KModel<typename Lane<V>::S>& km, const typename Lane<V>::S* __restrict__ drv,
+                                            const V (&rr)[3 * L::G], const V (&qq)[2],
+                                            V (&R)[L::SP], V (&S)[2], V (&C)[L::G], V& Tnew) {
+    V unused[L::G];
+    member_step<V, L, false>(km, drv, rr, qq, R, S, C, Tnew, unused);
 }
 
 // The shared model is the FIRST kernel argument (by value): its bytes sit at offset 0 of the
@@ -400,6 +521,48 @@ __device__ __forceinline__ void wave_stats(const bool active, const T Tn, double
     }
 }
 
+// Packed lanes (two members per lane): the wave covers 128 consecutive members, lanes 0..31 the first 64 and lanes
+// 32..63 the second 64, so the ladder stops one step early (no row_bcast:31) and lane 31 / lane 63 write the two
+// 64-member records — the record layout [ceil(N/64)][n_steps][4] is the same for every kernel shape.
+template <typename Op>
+__device__ __forceinline__ double wave_reduce_to_lanes_31_63(double v, const double neutral) {
+    v = Op::f(v, dpp_move_f64<0x111, 0xf>(v, neutral));   // row_shr:1
+    v = Op::f(v, dpp_move_f64<0x112, 0xf>(v, neutral));   // row_shr:2
+    v = Op::f(v, dpp_move_f64<0x114, 0xf>(v, neutral));   // row_shr:4
+    v = Op::f(v, dpp_move_f64<0x118, 0xf>(v, neutral));   // row_shr:8
+    v = Op::f(v, dpp_move_f64<0x142, 0xa>(v, neutral));   // row_bcast:15 into rows 1 and 3 -> lanes 31, 63 = half totals
+    return v;
+}
+__device__ __forceinline__ void wave_stats(const bool a0, const bool a1, const float2v Tn, double* __restrict__ out_lo,
+                                           double* __restrict__ out_hi /* nullptr: the wave has <= 64 members */) {
+    const double inf = __builtin_inf();
+    const double x = (double)Tn.x, y = (double)Tn.y;
+    const double s1 = wave_reduce_to_lanes_31_63<OpAdd>((a0 ? x : 0.0) + (a1 ? y : 0.0), 0.0);
+    const double s2 = wave_reduce_to_lanes_31_63<OpAdd>((a0 ? x * x : 0.0) + (a1 ? y * y : 0.0), 0.0);
+    const double mn = wave_reduce_to_lanes_31_63<OpMin>(fmin(a0 ? x : inf, a1 ? y : inf), inf);
+    const double mx = wave_reduce_to_lanes_31_63<OpMax>(fmax(a0 ? x : -inf, a1 ? y : -inf), -inf);
+    const int lane = threadIdx.x & 63;
+    double* const out = lane == 31 ? out_lo : (lane == 63 ? out_hi : nullptr);
+    if (out != nullptr) {
+        out[0] = s1;
+        out[1] = s2;
+        out[2] = mn;
+        out[3] = mx;
+    }
+}
+
+// Row access of a lane: one element (scalar lanes) or two consecutive elements as ONE 8-byte access (packed lanes; the
+// host guarantees even row strides and 8-byte aligned rows before it picks a packed kernel).  `full` = both members of
+// a packed lane exist; the last lane of an odd ensemble stores its first member only.
+template <typename V>
+__device__ __forceinline__ V load_lane(const typename Lane<V>::S* p) { return *reinterpret_cast<const V*>(p); }
+__device__ __forceinline__ void store_lane(double* p, double v, bool) { *p = v; }
+__device__ __forceinline__ void store_lane(float* p, float v, bool) { *p = v; }
+__device__ __forceinline__ void store_lane(float* p, float2v v, bool full) {
+    if (full) *reinterpret_cast<float2v*>(p) = v;
+    else *p = v.x;
+}
+
 // ---------------------------------------------------------------------------------
 // The time-fused kernel produces one T per lane EVERY step, so it batches the statistics instead
 // of running the DPP ladder per step (which costs +20 % fp64 / +70 % fp32 there): each wave parks
@@ -449,6 +612,49 @@ __device__ __forceinline__ void wave_stats_flush(const T* tile /* [STAT_STEPS][S
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
+// Packed lanes: the tile row holds the wave's 64 float2 values (128 members); lane l owns step j = l % 8 and lanes
+// 8p .. 8p+7 of it (members 16p .. 16p+15), p = l / 8; p < 4 is the wave's first 64-member record, p >= 4 its second.
+__device__ __forceinline__ void wave_stats_flush(const float2v* tile /* [STAT_STEPS][STAT_ROW] */, const int count,
+                                                 const int n_valid /* members of this wave, <= 128 */,
+                                                 double* __restrict__ out_lo, double* __restrict__ out_hi, const int64_t stride) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (STAT_STEPS - 1), p = lane >> 3;
+    const double inf = __builtin_inf();
+    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = p * 8 + i;
+        const float2v v2 = tile[j * STAT_ROW + idx];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double v = (double)(c == 0 ? v2.x : v2.y);
+            if (2 * idx + c < n_valid) {
+                s1 += v;
+                s2 = __builtin_fma(v, v, s2);
+                mn = fmin(mn, v);
+                mx = fmax(mx, v);
+            }
+        }
+    }
+#pragma unroll
+    for (int sh = 8; sh < 32; sh <<= 1) {
+        s1 += __shfl_xor(s1, sh);
+        s2 += __shfl_xor(s2, sh);
+        mn = fmin(mn, __shfl_xor(mn, sh));
+        mx = fmax(mx, __shfl_xor(mx, sh));
+    }
+    double* const out = p == 0 ? out_lo : (p == 4 ? out_hi : nullptr);
+    if (out != nullptr && j < count) {
+        double* o = out + (int64_t)j * stride;
+        o[0] = s1;
+        o[1] = s2;
+        o[2] = mn;
+        o[3] = mx;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
 // ---------------------------------------------------------------------------------
 // Kernel 1 — ONE TIMESTEP PER LAUNCH (the north-star form).
 // Per member-step HBM traffic (elements): read SP + 2 (state) + 3G + 2 (params),
@@ -461,17 +667,24 @@ __device__ __forceinline__ void wave_stats_flush(const T* tile /* [STAT_STEPS][S
 // 256-thread workgroups with identical buffers, profiles/r01/ab_variants.txt) and owns the same
 // members in every launch.
 // ---------------------------------------------------------------------------------
-template <typename T, int P0, int P1, int P2>
+template <typename V, int P0, int P1, int P2>
 __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
-    const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t, const int64_t n, const int64_t ld,
-    const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
-    T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
-    const int n_rows, double* __restrict__ stats /* [n_waves][n_steps][4] or nullptr */) {
+    const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps, const int t,
+    const int64_t n, const int64_t ld,
+    const typename Lane<V>::S* __restrict__ r, const typename Lane<V>::S* __restrict__ q,
+    typename Lane<V>::S* __restrict__ R, typename Lane<V>::S* __restrict__ S,
+    typename Lane<V>::S* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */,
+    typename Lane<V>::S* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
+    const int n_rows, double* __restrict__ stats /* [ceil(n/64)][n_steps][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
+    using T = typename Lane<V>::S;
+    constexpr int W = Lane<V>::W;                 // members per lane
     __shared__ T drv[DRIVE_STRIDE];
-    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_STEP_BLOCK + threadIdx.x;
+    const int64_t m = ((int64_t)blockIdx.x * FIVEEQ_STEP_BLOCK + threadIdx.x) * W;     // this lane's first member
     const bool active = m < n;
-    const int64_t mm = active ? m : n - 1;      // idle tail lanes load a valid member and store nothing
+    const bool full = m + (W - 1) < n;            // every member of the lane exists
+    // idle tail lanes load a valid (aligned) member and store nothing
+    const int64_t mm = active ? m : ((n - 1) & ~(int64_t)(W - 1));
     // Issue order matters for the workgroup's critical path: first the (tiny) shared loads, then
     // all 19 row loads, and only then the LDS writes + barrier, so the staging round trip is
     // overlapped with the row round trip instead of preceding it (+1.3 % at 1M members, neutral
@@ -485,43 +698,49 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
     if (threadIdx.x < DRIVE_STRIDE) drv_v = drive[(int64_t)t * DRIVE_STRIDE + threadIdx.x];
     const KModel<T>& kmr = km_s;
 
-    T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G];
+    V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G];
 #pragma unroll
-    for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + mm];
+    for (int k = 0; k < L::SP; ++k) Rv[k] = load_lane<V>(R + k * ld + mm);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + mm];
+    for (int k = 0; k < 2; ++k) Sv[k] = load_lane<V>(S + k * ld + mm);
 #pragma unroll
-    for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + mm];
+    for (int k = 0; k < 3 * L::G; ++k) rr[k] = load_lane<V>(r + k * ld + mm);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
+    for (int k = 0; k < 2; ++k) qq[k] = load_lane<V>(q + k * ld + mm);
 
     if (threadIdx.x < NW) reinterpret_cast<T*>(&km_s)[threadIdx.x] = stage_v;
     if (threadIdx.x < DRIVE_STRIDE) drv[threadIdx.x] = drv_v;
     __syncthreads();
 
-    T Tn = T(0);
+    V Tn = (V)T(0);
     {
-        member_step<T, L>(kmr, drv, rr, qq, Rv, Sv, Cv, Tn);
+        member_step<V, L>(kmr, drv, rr, qq, Rv, Sv, Cv, Tn);
         if (active) {
 #pragma unroll
-        for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
+        for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+        for (int k = 0; k < 2; ++k) store_lane(S + k * ld + m, Sv[k], full);
         const int row = __builtin_amdgcn_readfirstlane((int)drv[7]);     // wave-uniform: scalar test + offsets
         if (row >= 0 && row < n_rows) {
             if (C_traj != nullptr) {
                 T* c = C_traj + (int64_t)row * L::G * ld + m;
 #pragma unroll
-                for (int g = 0; g < L::G; ++g) store_stream(c + g * ld, Cv[g]);
+                for (int g = 0; g < L::G; ++g) store_lane(c + g * ld, Cv[g], full);
             }
-            if (T_traj != nullptr) store_stream(T_traj + (int64_t)row * ld + m, Tn);
+            if (T_traj != nullptr) store_lane(T_traj + (int64_t)row * ld + m, Tn, full);
         }
         }
     }
     if (stats != nullptr) {
-        const int64_t n_waves = (n + 63) >> 6;
+        const int64_t n_rec = (n + 63) >> 6;                             // one record per 64 members
         const int64_t wave = (int64_t)blockIdx.x * (FIVEEQ_STEP_BLOCK / 64) + (threadIdx.x >> 6);
-        if (wave < n_waves) wave_stats(active, Tn, stats + (wave * n_steps + t) * 4);
+        if constexpr (W == 1) {
+            if (wave < n_rec) wave_stats(active, Tn, stats + (wave * n_steps + t) * 4);
+        } else {
+            if (2 * wave < n_rec)
+                wave_stats(active, full, Tn, stats + (2 * wave * n_steps + t) * 4,
+                           2 * wave + 1 < n_rec ? stats + ((2 * wave + 1) * n_steps + t) * 4 : nullptr);
+        }
     }
 }
 
@@ -536,44 +755,49 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
 // INV = true: concentration-driven form.  drive[t][0..2] are target concentrations, cumE [G][ld] is
 // per-member cumulative-emission state (in/out), and C_traj receives the DIAGNOSED EMISSIONS.
 // (112 VGPRs at fp64 4+1+1 = 4 waves/SIMD; launch-bounds hints for 5 or 6 waves spill: -3 % / -16 %.)
-template <typename T, int P0, int P1, int P2, bool INV>
+template <typename V, int P0, int P1, int P2, bool INV>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
-    const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
-    const int64_t n, const int64_t ld,
-    const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
-    T* __restrict__ cumE /* [G][ld], INV only */,
-    T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
-    const int n_rows, double* __restrict__ stats /* [n_waves][n_steps][4] or nullptr */) {
+    const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps,
+    const int t_begin, const int t_end, const int64_t n, const int64_t ld,
+    const typename Lane<V>::S* __restrict__ r, const typename Lane<V>::S* __restrict__ q,
+    typename Lane<V>::S* __restrict__ R, typename Lane<V>::S* __restrict__ S,
+    typename Lane<V>::S* __restrict__ cumE /* [G][ld], INV only */,
+    typename Lane<V>::S* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */,
+    typename Lane<V>::S* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
+    const int n_rows, double* __restrict__ stats /* [ceil(n/64)][n_steps][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
+    using T = typename Lane<V>::S;
+    constexpr int W = Lane<V>::W;                 // members per lane
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
-    __shared__ T stat_tile[FIVEEQ_BLOCK / 64][STAT_STEPS * STAT_ROW];
+    __shared__ V stat_tile[FIVEEQ_BLOCK / 64][STAT_STEPS * STAT_ROW];
     __shared__ KModel<T> km_s;
     stage_model(&km_s);
     const KModel<T>& kmr = km_s;
 
-    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
+    const int64_t m = ((int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x) * W;       // this lane's first member
     const bool active = m < n;
+    const bool full = m + (W - 1) < n;
     const int64_t mm = active ? m : 0;    // idle tail lanes shadow member 0 and store nothing
-    const int64_t n_waves = (n + 63) >> 6;
+    const int64_t n_rec = (n + 63) >> 6;                                             // statistics records: one per 64 members
     const int64_t wave = (int64_t)blockIdx.x * (FIVEEQ_BLOCK / 64) + (threadIdx.x >> 6);
-    const bool wave_live = stats != nullptr && wave < n_waves;
-    T* const tile = stat_tile[threadIdx.x >> 6];
-    const int n_valid = (int)min((int64_t)64, n - wave * 64);      // members of this wave (<= 0: none)
-    int ks = 0;                                                      // steps parked in the tile
+    const bool wave_live = stats != nullptr && wave * W < n_rec;
+    V* const tile = stat_tile[threadIdx.x >> 6];
+    const int n_valid = (int)min((int64_t)64 * W, n - wave * 64 * W);               // members of this wave (<= 0: none)
+    int ks = 0;                                                                      // steps parked in the tile
 
-    T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
+    V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
     if constexpr (INV) {
 #pragma unroll
         for (int g = 0; g < L::G; ++g) cum[g] = cumE[g * ld + mm];
     }
 #pragma unroll
-    for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + mm];
+    for (int k = 0; k < L::SP; ++k) Rv[k] = load_lane<V>(R + k * ld + mm);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + mm];
+    for (int k = 0; k < 2; ++k) Sv[k] = load_lane<V>(S + k * ld + mm);
 #pragma unroll
-    for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + mm];
+    for (int k = 0; k < 3 * L::G; ++k) rr[k] = load_lane<V>(r + k * ld + mm);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
+    for (int k = 0; k < 2; ++k) qq[k] = load_lane<V>(q + k * ld + mm);
 
     for (int tc = t_begin; tc < t_end; tc += FIVEEQ_FUSED_CHUNK) {
         const int nt = min(FIVEEQ_FUSED_CHUNK, t_end - tc);
@@ -583,7 +807,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
         __syncthreads();
         for (int k = 0; k < nt; ++k) {
             const T* d = &drv[k * DRIVE_STRIDE];
-            member_step<T, L, INV>(kmr, d, rr, qq, Rv, Sv, Cv, Tn, cum);
+            member_step<V, L, INV>(kmr, d, rr, qq, Rv, Sv, Cv, Tn, cum);
             // the output row is wave-uniform: read it once into an SGPR so that the row test is a
             // scalar branch and the row offsets are scalar arithmetic, not 64-bit VALU per lane
             const int row = __builtin_amdgcn_readfirstlane((int)d[7]);
@@ -592,16 +816,21 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
                     if (C_traj != nullptr) {
                         T* c = C_traj + (int64_t)row * L::G * ld + m;
 #pragma unroll
-                        for (int g = 0; g < L::G; ++g) store_stream(c + g * ld, Cv[g]);
+                        for (int g = 0; g < L::G; ++g) store_lane(c + g * ld, Cv[g], full);
                     }
-                    if (T_traj != nullptr) store_stream(T_traj + (int64_t)row * ld + m, Tn);
+                    if (T_traj != nullptr) store_lane(T_traj + (int64_t)row * ld + m, Tn, full);
                 }
             }
             if (wave_live) {
                 tile[ks * STAT_ROW + (threadIdx.x & 63)] = Tn;
                 if (++ks == STAT_STEPS || tc + k + 1 == t_end) {
                     const int64_t t_first = (int64_t)(tc + k + 1 - ks);
-                    wave_stats_flush(tile, ks, n_valid, stats + (wave * n_steps + t_first) * 4, 4);
+                    if constexpr (W == 1) {
+                        wave_stats_flush(tile, ks, n_valid, stats + (wave * n_steps + t_first) * 4, 4);
+                    } else {
+                        wave_stats_flush(tile, ks, n_valid, stats + (2 * wave * n_steps + t_first) * 4,
+                                         2 * wave + 1 < n_rec ? stats + ((2 * wave + 1) * n_steps + t_first) * 4 : nullptr, 4);
+                    }
                     ks = 0;
                 }
             }
@@ -609,9 +838,9 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     }
     if (active) {
 #pragma unroll
-        for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
+        for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+        for (int k = 0; k < 2; ++k) store_lane(S + k * ld + m, Sv[k], full);
         if constexpr (INV) {
 #pragma unroll
             for (int g = 0; g < L::G; ++g) cumE[g * ld + m] = cum[g];
@@ -934,22 +1163,35 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void stream_copy_kernel(const int64_t
 // Diagnostic — evaluate one of the hand-written math primitives over an array, so that tests can
 // pin each of them against a CPU libm to the ulp, independently of the model.
 // op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0), 3 sqrt (x > 0), 4 reciprocal (x > 0).
+// fp32 only: op + 8 evaluates the PACKED twin (two members per lane) of the same primitive on the element pairs
+// (x[2i], x[2i+1]) — it must give the scalar routine's bits (n even).
 // ---------------------------------------------------------------------------------
+template <typename V>
+__device__ __forceinline__ V math_probe_eval(const int op, const V v) {
+    switch (op) {
+        case 0: return fe_expm1_neg(v);
+        case 1: return fe_exp(v);
+        case 2: return fe_log(v);
+        case 3: return fe_sqrt(v);
+        default: return fe_rcp(v);
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void math_probe_kernel(const int op, const int64_t n,
                                                                   const T* __restrict__ x, T* __restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * FIVEEQ_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const T v = x[i];
-    T r;
-    switch (op) {
-        case 0: r = fe_expm1_neg(v); break;
-        case 1: r = fe_exp(v); break;
-        case 2: r = fe_log(v); break;
-        case 3: r = fe_sqrt(v); break;
-        default: r = fe_rcp(v); break;
+    if constexpr (sizeof(T) == 4) {
+        if (op >= 8) {
+            if (2 * i + 1 < n) {
+                const float2v r = math_probe_eval(op - 8, float2v{x[2 * i], x[2 * i + 1]});
+                y[2 * i] = r.x;
+                y[2 * i + 1] = r.y;
+            }
+            return;
+        }
     }
-    y[i] = r;
+    if (i >= n) return;
+    y[i] = math_probe_eval(op, x[i]);
 }
 
 // Same copy with 16 B per lane (the widest access, 1 KiB per wave-instruction) and four loads in

@@ -208,6 +208,13 @@ int fiveeq_run_tiled_f32(const fiveeq_model *model, int64_t n_members, int64_t l
 /* largest k_steps the tiled kernel accepts for n_bins (0 = no histogram); 0 for an invalid n_bins */
 int32_t fiveeq_tile_steps_f64(int32_t n_bins);
 int32_t fiveeq_tile_steps_f32(int32_t n_bins);
+/* The fp32 entry points (step / run / run_fused / run_ksteps / run_tiled / plan_create _f32) compute TWO members per
+ * lane with packed fp32 instructions and 8-byte row accesses whenever the rows allow it (ld even, every row pointer
+ * 8-byte aligned, n_members >= 2), and one member per lane otherwise; both give the same bits.  This switch forces the
+ * one-member-per-lane kernels (on = 0) or re-enables packing (on != 0, the default); returns the previous setting.
+ * Process-wide; meant for measurements and tests. */
+int fiveeq_set_f32_packing(int on);
+
 /* LDS bytes per workgroup the tile size is derived from: hipDeviceAttributeMaxSharedMemoryPerBlock of the calling
  * thread's current device (160 KiB on MI355X; the same figure is assumed when no device is visible). */
 int32_t fiveeq_tile_lds_bytes(void);
@@ -283,7 +290,9 @@ int fiveeq_stream_copy_wide_f64(int64_t n, const double *src, double *dst, void 
 
 /* new — diagnostic: y[i] = f(x[i]) with one of the kernels' own fp64 math primitives, so tests can
  * pin each against a CPU libm to the ulp.  op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0, finite normal),
- * 3 sqrt (x > 0, finite normal), 4 reciprocal (x > 0, finite normal). */
+ * 3 sqrt (x > 0, finite normal), 4 reciprocal (x > 0, finite normal).  _f32 only: op + 8 evaluates the PACKED twin of
+ * the primitive (two members per lane, fiveeq_set_f32_packing above) on the element pairs (x[2i], x[2i+1]), n even:
+ * it must return the scalar routine's bits. */
 int fiveeq_math_probe_f64(int32_t op, int64_t n, const double *x, double *y, void *stream);
 int fiveeq_math_probe_f32(int32_t op, int64_t n, const float *x, float *y, void *stream);
 
