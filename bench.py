@@ -33,16 +33,42 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+
+
+def _numpy_worker(argv):
+    """`bench.py --numpy-worker kind G members steps lo hi`: one process of the `numpy_nproc` CPU-baseline leg — advances
+    members [lo, hi) of the `members`-member sample with the NumPy oracle and prints its compute seconds.  No torch, no GPU."""
+    kind, G, n, steps, lo, hi = argv[0], int(argv[1]), int(argv[2]), int(argv[3]), int(argv[4]), int(argv[5])
+    from fiveeqscm_amd import emissions, params
+    from oracle import fiveeq_oracle as npo
+    p = params.sample_ensemble_shard(params.default_params(kind), n, lo, hi)
+    E = emissions.rcp_like_emissions(steps, G)
+    t0 = time.perf_counter()
+    npo.run(E, p, hi - lo)
+    print(f"numpy-worker {time.perf_counter() - t0:.6f}", flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--numpy-worker":
+    _numpy_worker(sys.argv[2:])
+    sys.exit(0)
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# Vector issue peak: 256 CUs x 4 SIMDs at 2.4 GHz.  A wave64 fp64 instruction occupies its SIMD for 4 cycles
-# (16 FMA lanes per clock: 78.6 TFLOP/s fp64 vector, the datasheet figure) -> 6.144e11 wave-instructions/s; a wave64
-# fp32 instruction for 2 (32 lanes per clock: 157.3 TFLOP/s fp32 vector) -> 1.229e12.  Integer / conversion / select
-# instructions in the stream are priced like the kernel's float type: an estimate, stated as such.
+# Vector issue peak, priced per wave-INSTRUCTION: 256 CUs x 4 SIMDs at 2.4 GHz, one wave64 instruction per 4 cycles.
+#   fp64: 16 FMA lanes per clock per SIMD — the datasheet's 78.6 TFLOP/s fp64 vector — is one v_fma_f64 per 4 cycles.
+#   fp32: the datasheet's 157.3 TFLOP/s is the PACKED rate: one v_pk_fma_f32 (two FMAs per lane) per 4 cycles.  The fp32
+#         kernels here are the packed ones (two members per lane), so 4 cycles per wave-instruction is their peak too; a
+#         scalar v_fma_f32 stream reaches half the datasheet FLOP/s at best (measured 3.6 cycles per instruction).
+# What this chip SUSTAINS on a pure stream of one instruction kind (8 waves/SIMD, tools/microbench/valu_rates.hip,
+# profiles/r03/valu_rates_microbench.txt) is quoted beside the peak: the clock it holds under a dense VALU stream (~1.9-2.0
+# GHz, SQ counters) is below 2.4 GHz.  Integer / conversion / select instructions in the stream are priced like the rest.
 SIMDS = 1024
 CLOCK_HZ = 2.4e9
-VALU_CYCLES_PER_INSTR = {"f64": 4.0, "f32": 2.0}
+VALU_CYCLES_PER_INSTR = {"f64": 4.0, "f32": 4.0}
+VALU_SUSTAINED_CYCLES = {"f64": {"v_fma_f64": 5.52, "v_add_f64": 4.93, "v_rcp_f64": 17.45},
+                         "f32": {"v_pk_fma_f32": 5.18, "v_pk_mul_f32": 5.00, "v_pk_add_f32": 4.81, "v_fma_f32": 3.58,
+                                 "v_rcp_f32": 8.41}}
 
 WORKLOADS = {
     # name: (param set, gases, members per GPU, description)
@@ -104,7 +130,29 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(kind, G, n_sample, n_steps):
+def numpy_nproc(kind, G, n_members, n_steps, n_proc):
+    """SURVEY 8d's second CPU leg: `n_proc` independent NumPy processes (one per usable core), each on a contiguous shard
+    of `n_members` members; reported on the compute wall time of the SLOWEST process (imports excluded).  Child processes
+    (fork + exec of a fresh interpreter that never touches the GPU)."""
+    import subprocess
+    bounds = [(r * n_members // n_proc, (r + 1) * n_members // n_proc) for r in range(n_proc)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--numpy-worker", kind, str(G), str(n_members),
+                               str(n_steps), str(lo_), str(hi_)], stdout=subprocess.PIPE, text=True, env=env)
+             for lo_, hi_ in bounds]
+    times = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=600)
+        line = [ln for ln in out.splitlines() if ln.startswith("numpy-worker")]
+        if pr.returncode != 0 or not line:
+            return {"error": f"worker failed (rc {pr.returncode})"}
+        times.append(float(line[0].split()[1]))
+    return {"value": n_members * n_steps / max(times), "processes": n_proc, "gases": G,
+            "sample": f"{n_members} members x {n_steps} steps over {n_proc} NumPy processes (one per usable core, contiguous "
+                      f"member shards), compute time of the slowest {max(times):.2f} s, fastest {min(times):.2f} s"}
+
+
+def cpu_baseline(kind, G, n_sample, n_steps, numpy_legs=False):
     """Time the plain-C oracle (oracle/fiveeq_oracle.c, OpenMP over members) and the NumPy oracle
     (one core) on a bounded sample of the same workload.  Baseline only.  The thread count is the
     fastest of {usable cores, 64, 32, 16} on a small probe, and is what `cores` reports."""
@@ -142,7 +190,21 @@ def cpu_baseline(kind, G, n_sample, n_steps):
             model = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
     except Exception:  # noqa: BLE001
         pass
+    extra = {"numpy_nproc": numpy_nproc(kind, G, 10_000 * usable, n_steps, usable)}
+    if numpy_legs:                      # SURVEY 8d in full: N = 1e5 on one core and on every core, CO2-only and multi-gas
+        for kind_, G_ in (("co2", 1), ("multigas", 3)):
+            pk = params.sample_ensemble(params.default_params(kind_), 100_000)
+            Ek = emissions.rcp_like_emissions(n_steps, G_)
+            t0 = time.perf_counter()
+            npo.run(Ek, pk, 100_000)
+            dt_k = time.perf_counter() - t0
+            extra[f"numpy_1core_1e5_{kind_}"] = {"value": 100_000 * n_steps / dt_k,
+                                                 "sample": f"100000 members x {n_steps} steps, {G_} gas(es), {dt_k:.2f} s"}
+            extra[f"numpy_nproc_1e5_{kind_}"] = numpy_nproc(kind_, G_, 100_000, n_steps, usable)
     return {
+        **extra,
+        "note": "baseline only: the C port on all usable cores is the strongest CPU figure and is `value`; the NumPy legs are "
+                "what SURVEY 8d planned (one core; one process per usable core on member shards)",
         "value": n_sample * n_steps / dt_c, "unit": "member-timesteps/s", "cores": cores, "kind": "port",
         "sample": f"{n_sample} members x {n_steps} steps, {G} gas(es), fp64, oracle/fiveeq_oracle.c "
                   f"(gcc -O2 -fopenmp, {cores} threads of {usable} usable; final state kept, trajectories not stored), "
@@ -287,10 +349,15 @@ def main():
         torch.cuda.synchronize(dev)
         barrier()
         torch.cuda.synchronize(dev)
+        done = torch.cuda.Event()
         t0 = time.perf_counter()
         t_next = run_steps(eng, t_from, a.steps, a.mode, k_steps)
+        done.record()                          # on the launch stream, behind the K-th step
+        while not done.query():                # spin on it: a blocking synchronise adds its wake-up latency (10-20 us) to
+            pass                               # every block, which is 2 % of a 20-step block and nothing of a long one
+        t1 = time.perf_counter()
         torch.cuda.synchronize(dev)
-        return time.perf_counter() - t0, t_next
+        return t1 - t0, t_next
 
     first, t_idx = timed_block(t_idx)
     blocks = [first]
@@ -306,7 +373,7 @@ def main():
     value = n_total * a.steps / elapsed
     timing = {"timed_repeats": repeats, "block_ms_min_median_max": [min(blocks) * 1e3, elapsed * 1e3, max(blocks) * 1e3],
               "first_block_ms_per_step": blocks[0] / a.steps * 1e3,
-              "clocked": "per rank: barrier, device sync, clock, K steps, device sync, clock; MAX over ranks afterwards; "
+              "clocked": "per rank: barrier, device sync, clock, K steps, spin until the stream has drained, clock; MAX over ranks afterwards; "
                          "median over the repeated K-step blocks"}
     if repeats > 1 and eng.T is not None:
         # the repeated blocks cycled through the scenario and overwrote stored rows with later passes: re-run the
@@ -342,6 +409,12 @@ def main():
     n_local = hi - lo
     valu_peak = SIMDS * CLOCK_HZ / VALU_CYCLES_PER_INSTR[a.dtype]
     tname = "double" if a.dtype == "f64" else "float"
+    wbytes = 8 if a.dtype == "f64" else 4
+    # fp32 runs the packed kernels (two members per lane) whenever the rows allow 8-byte accesses: even members per launch
+    packed = a.dtype == "f32" and n_local % 2 == 0 and (eng.chunk_members % 2 == 0)
+    lname = "float2 (two members per lane)" if packed else tname
+    vtag = a.dtype + ("x2" if packed else "")
+    members_per_wave = 128 if packed else 64
     pools3 = ",".join(str(x) for x in (eng.pools + [0, 0])[:3])
     fusedlike = a.mode in ("fused", "ksteps", "tiled") or (a.mode == "auto" and eng.auto_k_steps() > 1)
     if not fusedlike:
@@ -353,19 +426,31 @@ def main():
         samples = samples / (per_batch * n_launch)
         k_avg = float(samples.mean())
         achieved = A * members_per_launch / k_avg / 1e9
+        tkey = f"{a.workload}:{a.dtype}:{per_gpu}"
+        traffic = (load_profile_json("traffic.json", tkey) or {}).get("hbm_bytes_per_launch")
+        resident = wbytes * (eng.sum_pools + 2 + 3 * G + 2) * members_per_launch          # state + parameter rows of a launch
+        if resident <= 0.8 * (256 << 20):
+            note = (f"achieved = algorithmic bytes / kernel time.  At {int(members_per_launch)} members per launch the "
+                    f"{resident / 1e6:.0f} MB of state + parameters stay in the 256 MiB Infinity Cache between launches, so "
+                    "this is HBM-peak-priced algorithmic traffic, not bytes that crossed HBM; `hbm_resident` is the same "
+                    "kernel with nothing cached.")
+        else:
+            note = (f"achieved = algorithmic bytes / kernel time.  {resident / 1e6:.0f} MB of state + parameters per launch "
+                    "against a 256 MiB Infinity Cache: most of these bytes cross HBM every launch"
+                    + (" (chunk-major schedule: one member chunk at a time stays cached between its launches)."
+                       if n_launch > 1 else "."))
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": (load_profile_json("traffic.json", f"{a.workload}:{a.dtype}:{per_gpu}") or {}).get(
-                        "hbm_bytes_per_launch"),
-                    "kernel": f"fiveeq::step_kernel<{tname},{pools3}>",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": (f"profiles/traffic.json[{tkey}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                       "tools/collect_profiles.sh, calibrated on a known copy in the same pass — a committed "
+                                       "measurement of this kernel and size, NOT re-measured by this run")
+                    if traffic is not None else None,
+                    "kernel": f"fiveeq::step_kernel<{lname},{pools3}>",
                     "algorithmic_bytes_per_member_step": A, "members_per_launch": members_per_launch,
                     "algorithmic_bytes_per_launch": A * members_per_launch,
                     "avg_launch_us": k_avg * 1e6, "min_launch_us": float(samples.min()) * 1e6,
-                    "launches_timed": int(samples.size) * per_batch * n_launch,
-                    "note": "achieved = algorithmic bytes / kernel time.  At 1M members the 152 MB of state + parameters "
-                            "stay in the 256 MiB Infinity Cache between launches, so this is HBM-peak-priced algorithmic "
-                            "traffic, not bytes that crossed HBM; `hbm_resident` is the same kernel with nothing cached."}
-        kkey = f"step:{a.dtype}:{pools3}"
+                    "launches_timed": int(samples.size) * per_batch * n_launch, "note": note}
+        kkey = f"step:{vtag}:{pools3}"
     else:
         # the time-fused family: one launch covers `span` steps; price it per step with its own A
         if a.mode == "tiled":
@@ -394,25 +479,31 @@ def main():
         achieved = A * n_local / k_avg / 1e9
         roofline = {"bound": "fp64-valu" if a.dtype == "f64" else "fp32-valu", "unit": "wave-instr/s",
                     "achieved": None, "peak": valu_peak, "frac": None, "traffic": None,
-                    "kernel": f"fiveeq::{kname}<{tname},{pools3}>", "steps_per_launch": span,
+                    "kernel": f"fiveeq::{kname}<{tname if kname == 'tile_kernel' else lname},{pools3}>", "steps_per_launch": span,
                     "algorithmic_bytes_per_member_step": A, "members_per_launch": n_local,
                     "hbm_GBs_of_algorithmic_bytes": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
                     "avg_step_us_in_kernel": k_avg * 1e6, "launches_timed": int(samples.size) * reps,
                     "timed_as": f"{samples.size} whole {n_scen}-step scenario passes from the initial state",
                     "note": "time-fused family: state stays in registers, the kernel is bound by VALU issue, not HBM; "
                             "frac = VALU wave-instructions per second / (1024 SIMDs x 2.4 GHz / cycles per instruction)."}
-        kkey = f"{'fused' if kname == 'fused_kernel' else 'tile'}:{a.dtype}:{pools3}"
+        kkey = f"fused:{vtag}:{pools3}" if kname == "fused_kernel" else f"tile:{a.dtype}:{pools3}"
+        if kname == "tile_kernel":
+            members_per_wave = 64
     # VALU issue: instructions per wave-step from the committed SQ-counter pass (profiles/valu.json, produced by
     # tools/collect_profiles.sh with rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ...), times the waves this bench ran
     valu = load_profile_json("valu.json", kkey)
     if valu:
-        waves = -(-int(roofline["members_per_launch"]) // 64)
+        waves = -(-int(roofline["members_per_launch"]) // members_per_wave)
         rate = valu["valu_per_wave_step"] * waves / k_avg
-        issue = {"valu_wave_instr_per_wave_step": valu["valu_per_wave_step"], "wave_instr_per_s": rate,
-                 "peak_wave_instr_per_s": valu_peak, "frac": rate / valu_peak,
-                 "peak_def": f"1024 SIMDs x 2.4 GHz / {VALU_CYCLES_PER_INSTR[a.dtype]:.0f} cycles per wave64 {a.dtype} VALU "
-                             "instruction (78.6 TFLOP/s fp64 / 157.3 TFLOP/s fp32 vector FMA)",
-                 "source": "profiles/valu.json"}
+        issue = {"valu_wave_instr_per_wave_step": valu["valu_per_wave_step"], "members_per_wave": members_per_wave,
+                 "wave_instr_per_s": rate, "peak_wave_instr_per_s": valu_peak, "frac": rate / valu_peak,
+                 "peak_def": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction: the datasheet's 78.6 TFLOP/s fp64 "
+                             "(v_fma_f64) and 157.3 TFLOP/s fp32 (v_pk_fma_f32, the PACKED rate: the fp32 kernels are the "
+                             "packed ones)",
+                 "measured_sustained_cycles_per_instr": VALU_SUSTAINED_CYCLES[a.dtype],
+                 "measured_sustained_source": "profiles/r03/valu_rates_microbench.txt (pure streams, 8 waves/SIMD)",
+                 "clock_GHz_under_load": valu.get("clock_GHz_under_load"),
+                 "source": f"profiles/valu.json[{kkey}] (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ..., committed)"}
         if fusedlike:
             roofline["achieved"], roofline["frac"] = rate, issue["frac"]
         roofline["fp64_issue_frac" if a.dtype == "f64" else "fp32_issue_frac"] = issue["frac"]
@@ -494,7 +585,7 @@ def main():
     if summary_error is not None:
         out["summary"] = {"error": summary_error}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(kind, G, a.cpu_sample_members, n_scen)
+        out["cpu_baseline"] = cpu_baseline(kind, G, a.cpu_sample_members, n_scen, numpy_legs=a.numpy_baseline)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if summary_error is not None:

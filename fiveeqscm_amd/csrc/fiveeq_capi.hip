@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -376,12 +377,13 @@ int launch_tile(const RunArgs<T>& a, int t_begin, int t_end, double lo, double i
     const int64_t wgs = (int64_t)cus * (1024 / TILE_BLOCK);
     const dim3 grid((unsigned)(n_blocks < wgs ? n_blocks : wgs)), block(TILE_BLOCK);
     const size_t dyn = hist ? (size_t)(t_end - t_begin) * ((n_bins + 1) / 2) * 4 : 0;
+    static const int stagger = getenv("FIVEEQ_TILE_STAGGER") ? atoi(getenv("FIVEEQ_TILE_STAGGER")) : 0;
     switch (a.code) {
 #define X(p0, p1, p2)                                                                                        \
     case (p0) * 100 + (p1) * 10 + (p2): {                                                                    \
         auto kfn = tile_kernel<T, p0, p1, p2>;                                                               \
         hipLaunchKernelGGL(kfn, grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, \
-                           a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, hist);        \
+                           a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, hist, stagger); \
     } break;
         FIVEEQ_LAYOUTS(X)
 #undef X

@@ -883,7 +883,7 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
     const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
     T* __restrict__ C_traj, T* __restrict__ T_traj, const int n_rows, double* __restrict__ stats,
     const double hist_lo, const double hist_inv_w, const int n_bins,
-    unsigned long long* __restrict__ hist /* [n_steps][n_bins] or nullptr */) {
+    unsigned long long* __restrict__ hist /* [n_steps][n_bins] or nullptr */, const int stagger) {
     using L = Layout<P0, P1, P2>;
     extern __shared__ unsigned int h_s[];                 // [nt][hw] packed 16-bit pairs (hist != nullptr)
     __shared__ T drv[TILE_MAX_STEPS * DRIVE_STRIDE];
@@ -902,6 +902,9 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
         for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) h_s[i] = 0u;
     for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += TILE_BLOCK) drv[i] = drive[(int64_t)t_begin * DRIVE_STRIDE + i];
     __syncthreads();
+    // experiment knob (FIVEEQ_TILE_STAGGER): the waves that share a SIMD (w, w+4, w+8, w+12) start their block loops
+    // `stagger` x 3.4 us apart so that their load / compute / store phases do not coincide
+    for (int i = 0; i < (int)(threadIdx.x >> 8) * stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     auto flush = [&]() {
         for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) {

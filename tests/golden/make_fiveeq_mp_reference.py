@@ -24,7 +24,7 @@ sys.path.insert(0, HERE)
 import fiveeq_cases as cases  # noqa: E402
 
 mp.mp.dps = 50
-MEMBERS = [0, 7, 16, 17, 19, 23]          # two Latin-hypercube members and four corners (all-low, all-high, ...)
+MEMBERS = list(range(24))                 # ALL golden members: 16 of the Latin hypercube and the 8 corners of the box
 M = mp.mpf
 
 
@@ -78,18 +78,26 @@ def run_member(p, E, m, dt=1):
     return Cs, Ts
 
 
+def _one(arg):
+    kind, m = arg
+    mp.mp.dps = 50
+    p, _ = cases.members(kind)
+    Cs, Ts = run_member(p, cases.scenario(kind), m)
+    return ([[mp.nstr(Cs[t][g], 30) for g in range(len(Cs[t]))] for t in cases.STEPS],
+            [mp.nstr(Ts[t], 30) for t in cases.STEPS])
+
+
 def main():
     doc = {"generator": "tests/golden/make_fiveeq_mp_reference.py", "mpmath": mp.__version__, "digits": mp.mp.dps,
            "members": MEMBERS, "steps": cases.STEPS, "cases": {}}
-    for kind in ("co2", "multigas"):
-        p, _ = cases.members(kind)
-        E = cases.scenario(kind)
-        rec = {"C": [], "T": []}
-        for m in MEMBERS:
-            Cs, Ts = run_member(p, E, m)
-            rec["C"].append([[mp.nstr(Cs[t][g], 30) for g in range(len(Cs[t]))] for t in cases.STEPS])
-            rec["T"].append([mp.nstr(Ts[t], 30) for t in cases.STEPS])
-        doc["cases"][kind] = rec
+    import multiprocessing
+    with multiprocessing.Pool(min(6, os.cpu_count() or 1)) as pool:       # members are independent: a few at a time
+        for kind in ("co2", "multigas"):
+            rec = {"C": [], "T": []}
+            for C_rows, T_row in pool.map(_one, [(kind, m) for m in MEMBERS]):
+                rec["C"].append(C_rows)
+                rec["T"].append(T_row)
+            doc["cases"][kind] = rec
     path = os.path.join(HERE, "fiveeq_mp_reference.json")
     with open(path, "w") as fh:
         json.dump(doc, fh, separators=(",", ":"))

@@ -928,19 +928,26 @@ def test_temperature_only_storage(gpu):
         assert t_only.bytes_per_member_step("per_step") == 8 * (2 * 6 + 3 * 3 + 6 + 1)
 
 
+# fp32 budget against the fp64 oracle over 750 steps, at the level the kernels actually reach (measured worst over these
+# ensembles: 1.1e-5 relative on T, 1.2e-6 on C; profiles/r03/fp32_vs_fp64_sweep_1M.txt): 3e-5 on T, 5e-6 on C, with an
+# absolute floor of a few fp32 roundings of the quantity's scale (T of order 1 K, concentrations of order 300-2000).
+FP32_T = dict(rtol=3e-5, atol=2e-6)
+FP32_C = dict(rtol=5e-6, atol=2e-4)
+
+
 def test_fp32_kernel_tracks_fp64_oracle(gpu):
-    """BASELINE configs[4] runs fp32: stay within 2e-4 relative of the fp64 oracle over 750 steps
-    (increment-form updates keep the tau = 1e6 yr pool alive in fp32)."""
-    N = 2048
-    p = prm.sample_ensemble(prm.default_params("multigas"), N)
-    E = emi.rcp_like_emissions(750, 3)
-    want = npo.run(E, p, N)
-    for mode in ("per_step", "fused"):
-        eng = _engine(p, N, E, dtype=torch.float32)
-        eng.run(mode=mode)
-        torch.cuda.synchronize()
-        _close(eng.C.double(), want["C"], rtol=2e-4, atol=1e-5, what="C32")
-        _close(eng.T.double(), want["T"], rtol=2e-4, atol=1e-5, what="T32")
+    """BASELINE configs[4] runs fp32: stay within 3e-5 (T) / 5e-6 (C) relative of the fp64 oracle over 750 steps
+    (increment-form updates keep the tau = 1e6 yr pool alive in fp32) — packed lanes (even N) and scalar lanes (odd N)."""
+    for N in (2048, 2047):
+        p = prm.sample_ensemble(prm.default_params("multigas"), N)
+        E = emi.rcp_like_emissions(750, 3)
+        want = npo.run(E, p, N)
+        for mode in ("per_step", "fused"):
+            eng = _engine(p, N, E, dtype=torch.float32)
+            eng.run(mode=mode)
+            torch.cuda.synchronize()
+            _close(eng.C.double(), want["C"], what="C32", **FP32_C)
+            _close(eng.T.double(), want["T"], what="T32", **FP32_T)
 
 
 def test_sharding_invariance(gpu):
@@ -1084,8 +1091,8 @@ def test_full_size_config5_shard_fp32_sparse_outputs(gpu):
     assert torch.equal(a[:, 3:], b[:, 3:]) and torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-11, atol=1e-6)
     del hst
     want = c_oracle.run(E, blk, B, n_threads=8)
-    _close(eng.T[:, :B].double(), want["T"][years], rtol=1e-4, atol=1e-5, what="T tile0 fp32")
-    _close(eng.C[:, :, :B].double(), want["C"][years], rtol=1e-4, atol=1e-4, what="C tile0 fp32")
+    _close(eng.T[:, :B].double(), want["T"][years], what="T tile0 fp32", **FP32_T)
+    _close(eng.C[:, :, :B].double(), want["C"][years], what="C tile0 fp32", **FP32_C)
     full = (N // B) * B
     Tt = eng.T[:, :full].view(3, N // B, B)
     assert torch.equal(Tt, Tt[:, :1, :].expand_as(Tt))

@@ -47,6 +47,44 @@ def test_golden_member_set_is_the_committed_one(golden, kind):
 
 
 @pytest.mark.parametrize("kind", ["co2", "multigas"])
+def test_golden_inputs_cross_checked_without_the_product_helpers(golden, kind):
+    """tests/golden/fiveeq_cases.py builds the member set with PRODUCT helpers (params.default_params, params.k_q,
+    params.sample_ensemble_shard), so those are common-mode inputs of oracle and kernels.  Cross-check them from the
+    other side: (1) the 8 corner columns of the committed fixture are the corner table applied to the default centres,
+    with q recomputed by the ORACLE'S OWN k_q and a doubling forcing recomputed from the oracle's step_forc; (2) for the
+    16 Latin-hypercube columns the oracle's k_q maps the (TCR, ECS) the q rows imply — read back through the oracle's own
+    definitions ECS = F2x (q1 + q2), TCR = F2x (q1 k1 + q2 k2) — onto the same q, and those draws lie in the sampling box
+    of SURVEY 8d; (3) r0 / rC / rT sit inside their perturbation ranges around the centres."""
+    from fiveeqscm_amd import params as prm
+    rec = golden["cases"][kind]
+    G, N = (1 if kind == "co2" else 3), 24
+    base = prm.default_params(kind)
+    fix = {name: _arr(rec[name], (rows, N)) for name, rows in (("r0", G), ("rC", G), ("rT", G), ("q", 2))}
+    C0 = float(np.asarray(base["PI_conc"], dtype=np.float64).reshape(-1)[0])
+    f0 = np.asarray(base["f"], dtype=np.float64).reshape(-1, 3)[0]
+    F2x = float(npo.step_forc(np.array([2.0 * C0]), C0, f0)[0])                  # the oracle's forcing of a CO2 doubling
+    assert abs(F2x - prm.forcing_2x(base)) <= 1e-15 * F2x
+    d = np.asarray(base["d"], dtype=np.float64)
+    centre = {k: np.asarray(base[k], dtype=np.float64).reshape(G) for k in ("r0", "rC", "rT")}
+    for j, (s0, sC, sT, tcr, ecs) in enumerate(cases.CORNERS):
+        col = cases.N_LHS + j
+        for name, scale in (("r0", s0), ("rC", sC), ("rT", sT)):
+            assert np.array_equal(fix[name][:, col], centre[name] * scale), (name, j)
+        np.testing.assert_allclose(fix["q"][:, col], npo.k_q(tcr, ecs, d, F2x), rtol=1e-15, atol=0, err_msg=f"corner {j}")
+    k = 1.0 - (d / 70.0) * (-np.expm1(-70.0 / d))
+    q = fix["q"][:, :cases.N_LHS]
+    ecs, tcr = F2x * (q[0] + q[1]), F2x * (q[0] * k[0] + q[1] * k[1])
+    np.testing.assert_allclose(npo.k_q(tcr, ecs, d, F2x), q, rtol=1e-12, atol=0)
+    assert np.all((tcr >= 1.0 - 1e-12) & (tcr <= 2.5 + 1e-12)) and np.all((ecs >= 1.1 * tcr - 1e-12) & (ecs <= 4.5 + 1e-12))
+    for name, lo_s, hi_s in (("r0", 0.8, 1.2), ("rC", 0.5, 1.5), ("rT", 0.5, 1.5)):
+        live = centre[name] != 0.0                                            # a zero centre (no such feedback) stays zero
+        assert np.all(fix[name][~live] == 0.0), name
+        ratio = fix[name][live][:, :cases.N_LHS] / centre[name][live][:, None]
+        assert np.all((ratio >= lo_s - 1e-12) & (ratio <= hi_s + 1e-12)), name
+        assert ratio.max() - ratio.min() > 0.5 * (hi_s - lo_s)                # 16 strata: the draws spread over the range
+
+
+@pytest.mark.parametrize("kind", ["co2", "multigas"])
 def test_numpy_oracle_reproduces_its_golden_trajectories(golden, kind):
     p, N = cases.members(kind)
     rec = golden["cases"][kind]

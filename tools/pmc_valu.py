@@ -34,7 +34,8 @@ def main():
                     name = row["Kernel_Name"]
                     if "fiveeq::" not in name:
                         continue
-                    k = name.split("(")[0].replace("void ", "").strip()
+                    # packed fp32 lanes show up as "float __vector(2)": call them float2 before cutting the argument list off
+                    k = name.replace("float __vector(2)", "float2").split("(")[0].replace("void ", "").strip()
                     acc[(k, row["Counter_Name"])].append(float(row["Counter_Value"]))
                     dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
     with open(out_csv, "w") as fh:
@@ -49,7 +50,7 @@ def main():
             doc = json.load(fh)
     kernels = {k for k, _ in acc}
     for k in sorted(kernels):
-        m = re.match(r"fiveeq::(step|fused|tile)_kernel<(double|float), (\d), (\d), (\d)(?:, (true|false))?>", k)
+        m = re.match(r"fiveeq::(step|fused|tile)_kernel<(double|float2|float), (\d), (\d), (\d)(?:, (true|false))?>", k)
         if not m or m.group(6) == "true":
             continue
         mean = lambda c: (sum(acc[(k, c)]) / len(acc[(k, c)])) if (k, c) in acc else None   # noqa: E731
@@ -59,9 +60,15 @@ def main():
         steps = 1 if m.group(1) == "step" else fused_steps
         if m.group(1) == "tile":
             steps, waves = tile_k, float(-(-members // 64))
-        key = f"{m.group(1)}:{'f64' if m.group(2) == 'double' else 'f32'}:{m.group(3)},{m.group(4)},{m.group(5)}"
-        rec = {"kernel": k, "valu_per_wave_step": valu / waves / steps, "waves": waves, "steps_per_launch": steps,
+        per_wave = 128 if m.group(2) == "float2" else 64            # members of one wave: packed lanes carry two each
+        tag = {"double": "f64", "float": "f32", "float2": "f32x2"}[m.group(2)]
+        key = f"{m.group(1)}:{tag}:{m.group(3)},{m.group(4)},{m.group(5)}"
+        rec = {"kernel": k, "valu_per_wave_step": valu / waves / steps, "members_per_wave": per_wave,
+               "valu_per_member_step": valu / waves / steps / per_wave, "waves": waves, "steps_per_launch": steps,
                "dispatches": len(acc[(k, "SQ_INSTS_VALU")])}
+        gui, durs = mean("GRBM_GUI_ACTIVE"), dur.get(k)
+        if gui and durs:                                             # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles
+            rec["clock_GHz_under_load"] = gui / 8.0 / (sum(durs) / len(durs) * 1e-6) / 1e9
         for c, nm in (("SQ_INSTS_SALU", "salu_per_wave_step"), ("SQ_INSTS_LDS", "lds_per_wave_step"),
                       ("SQ_INSTS_VMEM_RD", "vmem_rd_per_wave_step"), ("SQ_INSTS_VMEM_WR", "vmem_wr_per_wave_step")):
             if mean(c) is not None:

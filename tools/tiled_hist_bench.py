@@ -49,6 +49,8 @@ def main():
     t_fused = timed(base, a.reps, mode="fused")
     print(f"{N} members {a.dtype} {a.steps} steps, no trajectory, stats on")
     print(f"  fused (stats only)            {t_fused / a.steps * 1e6:9.2f} us/step  {N * a.steps / t_fused:.3e} member-steps/s")
+    t_k32 = timed(base, a.reps, mode="ksteps", k_steps=32)
+    print(f"  fused kernel relaunched every 32 steps (ksteps)  {t_k32 / a.steps * 1e6:9.2f} us/step  {t_k32 / t_fused - 1:+.1%} vs fused")
     t_tile0 = timed(base, a.reps, mode="tiled")
     print(f"  tiled K={base.tile_steps():2d} (stats, no hist)  {t_tile0 / a.steps * 1e6:9.2f} us/step  "
           f"{t_tile0 / t_fused - 1:+.1%} vs fused")
