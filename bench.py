@@ -190,7 +190,7 @@ def cpu_baseline(kind, G, n_sample, n_steps, numpy_legs=False):
             model = next(line.split(":", 1)[1].strip() for line in fh if line.startswith("model name"))
     except Exception:  # noqa: BLE001
         pass
-    extra = {"numpy_nproc": numpy_nproc(kind, G, 10_000 * usable, n_steps, usable)}
+    extra = {"numpy_nproc": numpy_nproc(kind, G, 20_000 * usable, n_steps, usable)}
     if numpy_legs:                      # SURVEY 8d in full: N = 1e5 on one core and on every core, CO2-only and multi-gas
         for kind_, G_ in (("co2", 1), ("multigas", 3)):
             pk = params.sample_ensemble(params.default_params(kind_), 100_000)
@@ -201,14 +201,23 @@ def cpu_baseline(kind, G, n_sample, n_steps, numpy_legs=False):
             extra[f"numpy_1core_1e5_{kind_}"] = {"value": 100_000 * n_steps / dt_k,
                                                  "sample": f"100000 members x {n_steps} steps, {G_} gas(es), {dt_k:.2f} s"}
             extra[f"numpy_nproc_1e5_{kind_}"] = numpy_nproc(kind_, G_, 100_000, n_steps, usable)
+    c_port = {"value": n_sample * n_steps / dt_c, "cores": cores,
+              "sample": f"{n_sample} members x {n_steps} steps, {G} gas(es), fp64, oracle/fiveeq_oracle.c "
+                        f"(gcc -O2 -fopenmp, {cores} threads of {usable} usable; final state kept, trajectories not stored), "
+                        f"{dt_c:.2f} s"}
+    # `value` is the STRONGER of the two whole-box CPU figures: the NumPy oracle as one process per usable core on member
+    # shards (what north_star names: "the reference NumPy loop timed on the same box's host cores") or the C port under
+    # OpenMP.  NumPy's vectorised transcendentals beat the scalar-libm C loop per core, so it is usually the former.
+    nn = extra["numpy_nproc"]
+    best_numpy = "value" in nn and nn["value"] > c_port["value"]
     return {
         **extra,
-        "note": "baseline only: the C port on all usable cores is the strongest CPU figure and is `value`; the NumPy legs are "
-                "what SURVEY 8d planned (one core; one process per usable core on member shards)",
-        "value": n_sample * n_steps / dt_c, "unit": "member-timesteps/s", "cores": cores, "kind": "port",
-        "sample": f"{n_sample} members x {n_steps} steps, {G} gas(es), fp64, oracle/fiveeq_oracle.c "
-                  f"(gcc -O2 -fopenmp, {cores} threads of {usable} usable; final state kept, trajectories not stored), "
-                  f"{dt_c:.2f} s",
+        "c_port_openmp": c_port,
+        "note": "baseline only.  value = the stronger of (NumPy oracle, one process per usable core on contiguous member "
+                "shards) and (C port of the oracle, OpenMP over members); both are reported.",
+        "value": nn["value"] if best_numpy else c_port["value"], "unit": "member-timesteps/s",
+        "cores": nn["processes"] if best_numpy else cores, "kind": "port",
+        "sample": (f"oracle/fiveeq_oracle.py (numpy {np.__version__}): " + nn["sample"]) if best_numpy else c_port["sample"],
         "cpu_model": model,
         "numpy_1core": {"value": n_np * n_steps / dt_np, "sample": f"{n_np} members x {n_steps} steps, "
                         f"oracle/fiveeq_oracle.py, numpy {np.__version__}, {dt_np:.2f} s"},
@@ -344,6 +353,7 @@ def main():
         os._exit(17)
 
     def timed_block(t_from):
+        """One K-step block on the wall clock: barrier, device sync, clock, K steps, drained stream, clock."""
         if a.mode == "graph":                  # instantiate the block's graphs outside the timing
             prepare_graphs(t_from % n_scen, a.steps)
         torch.cuda.synchronize(dev)
@@ -353,28 +363,50 @@ def main():
         t0 = time.perf_counter()
         t_next = run_steps(eng, t_from, a.steps, a.mode, k_steps)
         done.record()                          # on the launch stream, behind the K-th step
-        while not done.query():                # spin on it: a blocking synchronise adds its wake-up latency (10-20 us) to
-            pass                               # every block, which is 2 % of a 20-step block and nothing of a long one
+        while not done.query():                # spin: a blocking synchronise would add its wake-up latency to the block
+            pass
         t1 = time.perf_counter()
         torch.cuda.synchronize(dev)
         return t1 - t0, t_next
 
     first, t_idx = timed_block(t_idx)
-    blocks = [first]
     first_max = max_over_ranks([first])[0]
-    repeats = 1
+    repeats, blocks, wall_all = 1, [first], None
     if a.min_timed_ms > 0 and first_max * 1e3 < a.min_timed_ms:
+        # A short block (the driver's 20-step call is 0.75 ms) is repeated, and the repeats run BACK TO BACK: one barrier +
+        # device sync before the first, then R x K steps enqueued with a HIP event on the launch stream at every block
+        # boundary, one drain at the end.  Block i = event i -> event i+1 on the device's own clock, so a block holds its K
+        # steps and nothing else — no idle-stream launch latency, no host wake-up — exactly what K steps cost inside a long
+        # run.  The wall clock around all R blocks is kept beside it as the cross-check.
         repeats = int(min(max(a.max_repeats, 1), -(-a.min_timed_ms * 1e-3 // max(first_max, 1e-6)))) | 1     # odd
-    for _ in range(repeats - 1):
-        dt_b, t_idx = timed_block(t_idx)
-        blocks.append(dt_b)
+        if a.mode == "graph":
+            prepare_graphs(t_idx % n_scen, a.steps * repeats)
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(repeats + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(repeats):
+            t_idx = run_steps(eng, t_idx, a.steps, a.mode, k_steps)
+            marks[i + 1].record()
+        while not marks[-1].query():
+            pass
+        wall_all = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        blocks = [marks[i].elapsed_time(marks[i + 1]) * 1e-3 for i in range(repeats)]
     blocks = max_over_ranks(blocks)                              # per block: the slowest rank
     elapsed = float(np.median(blocks))
     value = n_total * a.steps / elapsed
     timing = {"timed_repeats": repeats, "block_ms_min_median_max": [min(blocks) * 1e3, elapsed * 1e3, max(blocks) * 1e3],
-              "first_block_ms_per_step": blocks[0] / a.steps * 1e3,
-              "clocked": "per rank: barrier, device sync, clock, K steps, spin until the stream has drained, clock; MAX over ranks afterwards; "
-                         "median over the repeated K-step blocks"}
+              "first_block_ms_per_step": first_max / a.steps * 1e3,
+              "first_block_is": "ONE K-step block on the wall clock (barrier, device sync, clock, K steps, drained stream, "
+                                "clock; MAX over ranks): the contract's literal sample",
+              "wall_ms_per_step_over_all_repeats": None if wall_all is None else
+              max_over_ranks([wall_all])[0] / (a.steps * repeats) * 1e3,
+              "clocked": ("one K-step block on the wall clock (it is longer than --min-timed-ms)" if repeats == 1 else
+                          f"{repeats} K-step blocks enqueued back to back after one barrier + device sync; block = HIP event "
+                          "to HIP event on the launch stream; MAX over ranks per block, then the median block")}
     if repeats > 1 and eng.T is not None:
         # the repeated blocks cycled through the scenario and overwrote stored rows with later passes: re-run the
         # W + K steps of the first block from the initial state (untimed) so that the summary below is taken on the rows

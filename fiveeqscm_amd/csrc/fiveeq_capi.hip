@@ -328,9 +328,14 @@ const DeviceFacts& device_facts() {
 int device_cus() { return device_facts().cus; }
 int device_lds_bytes() { return device_facts().lds_bytes; }
 
+// static LDS of tile_kernel<V>: drive records + the statistics tiles (one lane VALUE per slot: 8 bytes for fp64 and for
+// the packed fp32 lanes, 4 for scalar fp32) + the staged model.  The fp32 entry points may run either the packed or the
+// scalar instantiation, so the tile size they advertise is the packed kernel's (the larger tile, the smaller K).
 template <typename T>
 constexpr int tile_static_lds() {
-    return (int)(sizeof(T) * (TILE_MAX_STEPS * DRIVE_STRIDE + (TILE_BLOCK / 64) * STAT_STEPS * STAT_ROW) + sizeof(KModel<T>));
+    constexpr int lane_bytes = 8;                          // double, or float2v
+    return (int)(sizeof(T) * TILE_MAX_STEPS * DRIVE_STRIDE + lane_bytes * (TILE_BLOCK / 64) * STAT_STEPS * STAT_ROW +
+                 sizeof(KModel<T>));
 }
 // largest K whose histogram [K][ceil(n_bins/2)] dwords fits beside the kernel's static LDS
 template <typename T>
@@ -353,11 +358,15 @@ int tile_prepare(int code, size_t dyn_needed) {
     if (code < 0 || code >= 1000) return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", code);
     if (done_dev[code] == dev + 1) return FIVEEQ_OK;
     const int dyn_max = device_lds_bytes() - tile_static_lds<T>();
+    using P = typename LaneOf<T>::Packed;
     switch (code) {
 #define X(p0, p1, p2)                                                                                        \
     case (p0) * 100 + (p1) * 10 + (p2):                                                                      \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<T, p0, p1, p2>),               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));                   \
+        if (!std::is_same<P, T>::value)                                                                      \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<P, p0, p1, p2>),           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));               \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X
@@ -372,7 +381,10 @@ int tile_prepare(int code, size_t dyn_needed) {
 template <typename T>
 int launch_tile(const RunArgs<T>& a, int t_begin, int t_end, double lo, double inv_w, int n_bins,
                 unsigned long long* hist, hipStream_t st) {
-    const int64_t n_blocks = (a.n + TILE_BLOCK - 1) / TILE_BLOCK;
+    using P = typename LaneOf<T>::Packed;
+    const bool packed = LaneOf<T>::can_pack(a);
+    const int64_t per_block = (int64_t)TILE_BLOCK * (packed ? 2 : 1);
+    const int64_t n_blocks = (a.n + per_block - 1) / per_block;
     const int cus = device_cus();
     const int64_t wgs = (int64_t)cus * (1024 / TILE_BLOCK);
     const dim3 grid((unsigned)(n_blocks < wgs ? n_blocks : wgs)), block(TILE_BLOCK);
@@ -380,11 +392,16 @@ int launch_tile(const RunArgs<T>& a, int t_begin, int t_end, double lo, double i
     static const int stagger = getenv("FIVEEQ_TILE_STAGGER") ? atoi(getenv("FIVEEQ_TILE_STAGGER")) : 0;
     switch (a.code) {
 #define X(p0, p1, p2)                                                                                        \
-    case (p0) * 100 + (p1) * 10 + (p2): {                                                                    \
-        auto kfn = tile_kernel<T, p0, p1, p2>;                                                               \
-        hipLaunchKernelGGL(kfn, grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, \
-                           a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, hist, stagger); \
-    } break;
+    case (p0) * 100 + (p1) * 10 + (p2):                                                                      \
+        if (packed)                                                                                          \
+            hipLaunchKernelGGL((tile_kernel<P, p0, p1, p2>), grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, \
+                               a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, \
+                               hist, stagger);                                                               \
+        else                                                                                                 \
+            hipLaunchKernelGGL((tile_kernel<T, p0, p1, p2>), grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, \
+                               a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, \
+                               hist, stagger);                                                               \
+        break;
         FIVEEQ_LAYOUTS(X)
 #undef X
         default:

@@ -221,9 +221,8 @@ __device__ __forceinline__ double fe_rcp(double a) {
     return __builtin_fma(y, e, y);
 }
 __device__ __forceinline__ float fe_rcp(float a) {
-    const float y = __builtin_amdgcn_rcpf(a);                // v_rcp_f32 (1 ulp) + one Newton step
-    return __builtin_fmaf(y, __builtin_fmaf(-a, y, 1.0f), y);
-}
+    return __builtin_amdgcn_rcpf(a);                         // v_rcp_f32: 1 ulp.  (A Newton step on top, <= 0.5 ulp, was 2 % of the
+}                                                            // fused fp32 kernel and moved no fp32-vs-fp64 figure: r03/ab_variants.txt)
 
 // ln(x) for finite normal x > 0 (a concentration ratio).  The classic fdlibm scheme:
 // x = 2^k (1+f) with sqrt(1/2) <= 1+f < sqrt(2);  s = f/(2+f);  ln(1+f) = f - f^2/2 + s (f^2/2 + R(s^2))
@@ -322,8 +321,7 @@ __device__ __forceinline__ float2v fe_exp(float2v x) {
     return fe_fma(e, lo * F32_LN2, e);
 }
 __device__ __forceinline__ float2v fe_rcp(float2v a) {
-    const float2v y = float2v{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
-    return fe_fma(y, fe_fma(-a, y, (float2v)1.0f), y);
+    return float2v{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
 }
 __device__ __forceinline__ float2v fe_log(float2v x) {
     float mx = __builtin_amdgcn_frexp_mantf(x.x), my = __builtin_amdgcn_frexp_mantf(x.y);
@@ -380,6 +378,9 @@ __device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, con
     V G_u;
     if constexpr (INV) G_u = cum[g] - G_a;
     else G_u = drv[3 + g] - G_a;
+    // (skipping the ra and f2 terms behind wave-uniform tests of those coefficients — zero in most default gases — was
+    // tried: 8 fewer instructions per member-step and +2.5 % fused fp32 / +3 % fused fp64; the branches cost more than
+    // they save, r03/ab_variants.txt)
     V iirf = fma3<V>(kg.ra, G_a, fma3<V>(rr[3 * g + 2], T_old, fma3<V>(rr[3 * g + 1], G_u, rr[3 * g])));
     iirf = fe_min(iirf, km.iirf_max);
     const V alpha = kg.g0 * fe_exp(iirf * kg.inv_g1);
@@ -874,20 +875,40 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
 #endif
 constexpr int TILE_BLOCK = FIVEEQ_TILE_BLOCK;
 constexpr int TILE_MAX_STEPS = 32;
-constexpr int TILE_FLUSH_BLOCKS = 65535 / TILE_BLOCK;      // 63 * 1024 = 64512 <= 65535
+// blocks a workgroup may histogram before it flushes: a 16-bit lane of the packed LDS counters must not overflow
+template <typename V>
+constexpr int tile_flush_blocks() { return 65535 / (TILE_BLOCK * Lane<V>::W); }      // 63 x 1024 (31 x 2048) <= 65535
 
-template <typename T, int P0, int P1, int P2>
+// bin of one value: hist_rows_kernel's rule, bit for bit
+__device__ __forceinline__ void tile_hist_add(unsigned int* h_row, const double v, const double lo, const double inv_w,
+                                              const int n_bins) {
+    if (v == v) {
+        const double pos = (v - lo) * inv_w;
+        const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
+        atomicAdd(&h_row[b >> 1], (b & 1) ? 0x10000u : 1u);
+    }
+}
+
+// V = lane value type: one member per lane, or two (packed fp32: a block is 2048 members and the kernel keeps the fused
+// packed kernel's 4 waves/SIMD x 2 members, where the one-member fp32 form is held to 4 waves x 1 by its 1024-thread
+// workgroup — SQ counters, profiles/r03/tile_vs_ksteps_K32_f32_4M.csv: at 4 waves/SIMD its VALU issues 24 % less densely
+// than the 6-wave fused kernel's).
+template <typename V, int P0, int P1, int P2>
 __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
-    const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
-    const int64_t n, const int64_t ld,
-    const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R, T* __restrict__ S,
-    T* __restrict__ C_traj, T* __restrict__ T_traj, const int n_rows, double* __restrict__ stats,
-    const double hist_lo, const double hist_inv_w, const int n_bins,
+    const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps,
+    const int t_begin, const int t_end, const int64_t n, const int64_t ld,
+    const typename Lane<V>::S* __restrict__ r, const typename Lane<V>::S* __restrict__ q,
+    typename Lane<V>::S* __restrict__ R, typename Lane<V>::S* __restrict__ S,
+    typename Lane<V>::S* __restrict__ C_traj, typename Lane<V>::S* __restrict__ T_traj, const int n_rows,
+    double* __restrict__ stats, const double hist_lo, const double hist_inv_w, const int n_bins,
     unsigned long long* __restrict__ hist /* [n_steps][n_bins] or nullptr */, const int stagger) {
     using L = Layout<P0, P1, P2>;
+    using T = typename Lane<V>::S;
+    constexpr int W = Lane<V>::W;
+    constexpr int BLOCK_MEMBERS = TILE_BLOCK * W;
     extern __shared__ unsigned int h_s[];                 // [nt][hw] packed 16-bit pairs (hist != nullptr)
     __shared__ T drv[TILE_MAX_STEPS * DRIVE_STRIDE];
-    __shared__ T stat_tile[TILE_BLOCK / 64][STAT_STEPS * STAT_ROW];
+    __shared__ V stat_tile[TILE_BLOCK / 64][STAT_STEPS * STAT_ROW];
     __shared__ KModel<T> km_s;
     {
         constexpr int NW = sizeof(KModel<T>) / sizeof(T);
@@ -903,7 +924,7 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
     for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += TILE_BLOCK) drv[i] = drive[(int64_t)t_begin * DRIVE_STRIDE + i];
     __syncthreads();
     // experiment knob (FIVEEQ_TILE_STAGGER): the waves that share a SIMD (w, w+4, w+8, w+12) start their block loops
-    // `stagger` x 3.4 us apart so that their load / compute / store phases do not coincide
+    // `stagger` x 3.4 us apart so that their load / compute / store phases do not coincide (no effect: r03/ab_variants.txt)
     for (int i = 0; i < (int)(threadIdx.x >> 8) * stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     auto flush = [&]() {
@@ -919,65 +940,71 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
         }
     };
 
-    const int64_t n_blocks = (n + TILE_BLOCK - 1) / TILE_BLOCK;
-    const int64_t n_waves = (n + 63) >> 6;
-    T* const tile = stat_tile[threadIdx.x >> 6];
+    const int64_t n_blocks = (n + BLOCK_MEMBERS - 1) / BLOCK_MEMBERS;
+    const int64_t n_rec = (n + 63) >> 6;                                   // statistics records: one per 64 members
+    V* const tile = stat_tile[threadIdx.x >> 6];
     int since_flush = 0;
     for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const int64_t m = blk * TILE_BLOCK + threadIdx.x;
+        const int64_t m = (blk * TILE_BLOCK + threadIdx.x) * W;           // this lane's first member
         const bool active = m < n;
+        const bool full = m + (W - 1) < n;
         const int64_t mm = active ? m : 0;
         const int64_t wave = blk * (TILE_BLOCK / 64) + (threadIdx.x >> 6);
-        const bool wave_live = stats != nullptr && wave < n_waves;
-        const int n_valid = (int)min((int64_t)64, n - wave * 64);
+        const bool wave_live = stats != nullptr && wave * W < n_rec;
+        const int n_valid = (int)min((int64_t)64 * W, n - wave * 64 * W);
         int ks = 0;
 
-        T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
+        V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
 #pragma unroll
-        for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + mm];
+        for (int k = 0; k < L::SP; ++k) Rv[k] = load_lane<V>(R + k * ld + mm);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + mm];
+        for (int k = 0; k < 2; ++k) Sv[k] = load_lane<V>(S + k * ld + mm);
 #pragma unroll
-        for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + mm];
+        for (int k = 0; k < 3 * L::G; ++k) rr[k] = load_lane<V>(r + k * ld + mm);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
+        for (int k = 0; k < 2; ++k) qq[k] = load_lane<V>(q + k * ld + mm);
 
         for (int k = 0; k < nt; ++k) {
             const T* d = &drv[k * DRIVE_STRIDE];
-            member_step<T, L>(kmr, d, rr, qq, Rv, Sv, Cv, Tn);
+            member_step<V, L>(kmr, d, rr, qq, Rv, Sv, Cv, Tn);
             const int row = __builtin_amdgcn_readfirstlane((int)d[7]);
             if (row >= 0 && row < n_rows && active) {
                 if (C_traj != nullptr) {
                     T* c = C_traj + (int64_t)row * L::G * ld + m;
 #pragma unroll
-                    for (int g = 0; g < L::G; ++g) store_stream(c + g * ld, Cv[g]);
+                    for (int g = 0; g < L::G; ++g) store_lane(c + g * ld, Cv[g], full);
                 }
-                if (T_traj != nullptr) store_stream(T_traj + (int64_t)row * ld + m, Tn);
+                if (T_traj != nullptr) store_lane(T_traj + (int64_t)row * ld + m, Tn, full);
             }
             if (do_hist) {
-                const double v = (double)Tn;
-                if (active && v == v) {
-                    const double pos = (v - hist_lo) * hist_inv_w;
-                    const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
-                    atomicAdd(&h_s[k * hw + (b >> 1)], (b & 1) ? 0x10000u : 1u);
+                if constexpr (W == 1) {
+                    if (active) tile_hist_add(&h_s[k * hw], (double)Tn, hist_lo, hist_inv_w, n_bins);
+                } else {
+                    if (active) tile_hist_add(&h_s[k * hw], (double)Tn.x, hist_lo, hist_inv_w, n_bins);
+                    if (full) tile_hist_add(&h_s[k * hw], (double)Tn.y, hist_lo, hist_inv_w, n_bins);
                 }
             }
             if (wave_live) {
                 tile[ks * STAT_ROW + (threadIdx.x & 63)] = Tn;
                 if (++ks == STAT_STEPS || k + 1 == nt) {
                     const int64_t t_first = (int64_t)(t_begin + k + 1 - ks);
-                    wave_stats_flush(tile, ks, n_valid, stats + (wave * n_steps + t_first) * 4, 4);
+                    if constexpr (W == 1) {
+                        wave_stats_flush(tile, ks, n_valid, stats + (wave * n_steps + t_first) * 4, 4);
+                    } else {
+                        wave_stats_flush(tile, ks, n_valid, stats + (2 * wave * n_steps + t_first) * 4,
+                                         2 * wave + 1 < n_rec ? stats + ((2 * wave + 1) * n_steps + t_first) * 4 : nullptr, 4);
+                    }
                     ks = 0;
                 }
             }
         }
         if (active) {
 #pragma unroll
-            for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
+            for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+            for (int k = 0; k < 2; ++k) store_lane(S + k * ld + m, Sv[k], full);
         }
-        if (do_hist && ++since_flush == TILE_FLUSH_BLOCKS) {     // uniform over the workgroup
+        if (do_hist && ++since_flush == tile_flush_blocks<V>()) {     // uniform over the workgroup
             __syncthreads();
             flush();
             __syncthreads();

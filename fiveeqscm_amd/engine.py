@@ -19,6 +19,7 @@ HIP library, raises.  (The reference's own function, `calculate_hfc_conc`, is a
 NumPy one-liner and lives in fiveeqscm_amd.concentrations.)
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -156,6 +157,9 @@ class EnsembleEngine:
                 w_ = 8 if dtype == torch.float64 else 4       # costs one state + parameter round trip through HBM
                 hist_ring_steps = min(128, max(8, (8 << 30) // (2 * N * w_)))
             self.hist_ring_steps = max(1, min(int(hist_ring_steps), self.n_steps))
+            # where the streamed pipeline's histogram pass runs: "side" = a second HIP stream beside the next chunk's fused
+            # kernel, "same" = behind each chunk on the caller's stream (see _run_fused_streamed_hist)
+            self.hist_pass_stream = os.environ.get("FIVEEQ_HIST_PASS_STREAM", "side")
             self._ring = None            # allocated by the first streamed-histogram run
         if chunk_members == "auto":
             chunk_members = self.auto_chunk(N, SP, G, dtype)
@@ -451,7 +455,7 @@ class EnsembleEngine:
         ring = self._hist_ring()
         S = ring["S"]
         main = stream if stream is not None else torch.cuda.current_stream(dev)
-        side = ring["side"]
+        side = main if self.hist_pass_stream == "same" else ring["side"]
         side.wait_stream(main)                   # T_hist / self.T may have been touched on the caller's stream
         fused = getattr(self.lib, f"fiveeq_run_fused_{self._sfx}")
         with_stats = self._step_sums is not None

@@ -36,6 +36,10 @@ def test_default_mode_line_has_the_contract_keys():
     assert "workload" in d["config"] and "model" not in d["config"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["numpy_nproc"]["processes"] >= 1 and c["c_port_openmp"]["value"] > 0 and c["numpy_1core"]["value"] > 0
+    assert c["value"] == max(c["numpy_nproc"]["value"], c["c_port_openmp"]["value"])          # the stronger whole-box figure
+    assert r["traffic_source"] is None or "traffic.json" in r["traffic_source"]
+    assert d["timed_repeats"] == 1 or d["timing"]["wall_ms_per_step_over_all_repeats"] >= d["ms_per_step"] * 0.98
     s = d["summary"]
     assert len(s["T_mean"]) == len(s["years"]) and s["bytes_to_root"] == 0 and s["gather_ms"] > 0
 

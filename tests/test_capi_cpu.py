@@ -179,7 +179,7 @@ def test_new_entry_points_validate_on_the_host():
     assert tiled(33, 0.0, 1.0, 0, None) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
     assert tiled(lib.fiveeq_tile_steps_f64(4096) + 1, 0.0, 1.0, 4096, p) == _capi.E_INVALID
     # the LDS budget: K x 8 KiB of histogram beside the kernel's statistics tiles and drive table
-    assert lib.fiveeq_tile_steps_f64(4096) == 11 and lib.fiveeq_tile_steps_f32(4096) == 15
+    assert lib.fiveeq_tile_steps_f64(4096) == 11 and lib.fiveeq_tile_steps_f32(4096) == 11
     assert lib.fiveeq_tile_steps_f64(0) == 32 and lib.fiveeq_tile_steps_f32(1024) == 32
     assert lib.fiveeq_tile_steps_f64(-1) == 0 and lib.fiveeq_tile_steps_f32(4097) == 0
     stats = lambda rows, moments: lib.fiveeq_hist_rows_stats_f32(2, 100, 100, rows, 0.0, 1.0, 16, p, moments, None)   # noqa: E731

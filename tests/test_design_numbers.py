@@ -1,0 +1,64 @@
+"""Every number DESIGN.md quotes from a tracked JSON file must be IN that file.
+
+A cell that quotes a measurement writes it as   **number** (`file.json[key].field.sub` / scale)   — the bold number, then in
+backticks the tracked file (under profiles/ or profiles/r03/), an optional top-level [key] (keys of valu.json / traffic.json
+contain ':' and ','), a dotted path, and an optional '/ scale' or 'x scale'.  This test parses all of them and fails on a
+mismatch beyond the rounding of the printed digits (plus 0.2 %), so that the document cannot drift from the files the way
+round 2's did (391 vs 374.4 VALU per wave-step).  It also pins profiles/valu.json and profiles/traffic.json — the copies
+bench.py reads — to the round's collection under profiles/r03/."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CITE = re.compile(r"\*\*(?P<num>[-+]?[0-9][0-9.,]*(?:e[-+]?[0-9]+)?)\*\*[^`|\n]{0,40}?\(`(?P<file>[A-Za-z0-9_./-]+\.json)"
+                  r"(?:\[(?P<key>[^\]]+)\])?(?P<path>(?:\.[A-Za-z0-9_]+)+)`(?:\s*(?P<op>[/x])\s*(?P<scale>[0-9.e+-]+))?\)")
+
+
+def _resolve(name):
+    for base in ("profiles", os.path.join("profiles", "r03"), ""):
+        path = os.path.join(ROOT, base, name)
+        if os.path.exists(path):
+            return path
+    raise AssertionError(f"DESIGN.md cites {name}, which is not a tracked file under profiles/")
+
+
+def _lookup(doc, key, path):
+    if key is not None:
+        doc = doc[key]
+    for part in path.strip(".").split("."):
+        doc = doc[int(part)] if isinstance(doc, list) else doc[part]
+    return float(doc)
+
+
+def test_design_md_numbers_are_in_the_files_they_cite():
+    with open(os.path.join(ROOT, "DESIGN.md")) as fh:
+        text = fh.read()
+    cites = list(CITE.finditer(text))
+    assert len(cites) >= 12, f"only {len(cites)} file-backed numbers found in DESIGN.md: the citation format changed?"
+    cache, bad = {}, []
+    for m in cites:
+        path = _resolve(m["file"])
+        if path not in cache:
+            with open(path) as fh:
+                cache[path] = json.load(fh)
+        try:
+            val = _lookup(cache[path], m["key"], m["path"])
+        except (KeyError, IndexError, TypeError) as exc:
+            bad.append(f"{m.group(0)}: no such entry ({exc!r})")
+            continue
+        if m["scale"]:
+            val = val / float(m["scale"]) if m["op"] == "/" else val * float(m["scale"])
+        shown = m["num"].replace(",", "")
+        digits = len(shown.split(".")[1].split("e")[0]) if "." in shown else 0
+        exp = float("1" + shown[shown.index("e"):]) if "e" in shown else 1.0
+        tol = 0.5 * 10.0 ** (-digits) * exp + 2e-3 * abs(val)
+        if abs(float(shown) - val) > tol:
+            bad.append(f"DESIGN.md says {shown}, {m['file']}{'[' + m['key'] + ']' if m['key'] else ''}{m['path']} holds {val:.6g}")
+    assert not bad, "\n".join(bad)
+
+
+def test_bench_reads_this_rounds_counter_files():
+    for name in ("valu.json", "traffic.json"):
+        with open(os.path.join(ROOT, "profiles", name)) as a, open(os.path.join(ROOT, "profiles", "r03", name)) as b:
+            assert json.load(a) == json.load(b), f"profiles/{name} is not profiles/r03/{name}"

@@ -321,6 +321,26 @@ def test_packed_fp32_lanes_equal_scalar_lanes_bit_for_bit(gpu):
                     assert torch.allclose(ra[:, :, :2], rb[:, :, :2], rtol=1e-13, atol=1e-11), (kind, N, mode)
                     a.close()
                     b.close()
+        # the time-tiled kernel: packed blocks are 2048 members; its in-loop histogram must count every member once
+        E = emi.rcp_like_emissions(750, 3)[255:255 + n_steps]
+        for N in (2, 130, 2050, 4098, 20_000):
+            p = prm.sample_ensemble(prm.default_params("multigas"), N, seed=N)
+            runs = []
+            for packing in (1, 0):
+                lib.fiveeq_set_f32_packing(packing)
+                eng = _engine(p, N, E, dtype=torch.float32, collect_stats=True, hist=(-1.0, 5.0, 1000))
+                eng.run(mode="tiled", k_steps=int(rng.integers(0, 12)))
+                torch.cuda.synchronize()
+                runs.append(eng)
+            a, b = runs
+            for name in ("C", "T", "R", "S", "T_hist"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), ("tiled", N, name)
+            assert a.T_hist.sum(1).tolist() == [N] * n_steps
+            assert torch.equal(a.T_hist, a.T_histogram(-1.0, 5.0, 1000))
+            sa, sb = a.stats_sums(), b.stats_sums()
+            assert torch.equal(sa[:, [0, 3, 4]], sb[:, [0, 3, 4]]) and torch.allclose(sa[:, 1:3], sb[:, 1:3], rtol=1e-13, atol=1e-11)
+            a.close()
+            b.close()
         # an odd member count inside an even-strided allocation (the last packed lane stores one member only), and a
         # sub-range that starts at an odd member (not 8-byte aligned: the scalar kernels must take over) — through the raw
         # C ABI, members outside the range untouched
@@ -1206,7 +1226,7 @@ def test_tiled_kernel_lds_limit_is_set_once_per_instantiation(gpu):
     from fiveeqscm_amd import _capi
     lib = _capi.load()
     assert lib.fiveeq_tile_lds_bytes() == 160 * 1024
-    assert lib.fiveeq_tile_steps_f64(4096) == 11 and lib.fiveeq_tile_steps_f32(4096) == 15
+    assert lib.fiveeq_tile_steps_f64(4096) == 11 and lib.fiveeq_tile_steps_f32(4096) == 11
     N, n_steps = 2000, 66
     E = emi.rcp_like_emissions(750, 3)[250:250 + n_steps]
     p = prm.sample_ensemble(prm.default_params("multigas"), N)
@@ -1215,7 +1235,7 @@ def test_tiled_kernel_lds_limit_is_set_once_per_instantiation(gpu):
         for rep in range(3):
             eng = _engine(p, N, E, dtype=(torch.float64, torch.float32)[layout_case], store_trajectory=False,
                           hist=(-1.0, 5.0, 4096))
-            eng.run(mode="tiled")                          # 6 launches of 11 (fp64) / 5 of 15 (fp32) steps, 88 / 120 KiB of LDS each
+            eng.run(mode="tiled")                          # 6 launches of 11 steps, 88 KiB of histogram in LDS each
             torch.cuda.synchronize()
             assert eng.T_hist.sum(1).tolist() == [N] * n_steps
             counts.append(lib.fiveeq_tile_attr_calls())
