@@ -55,14 +55,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--numpy-worker":
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# Vector issue peak, priced per wave-INSTRUCTION: 256 CUs x 4 SIMDs at 2.4 GHz, one wave64 instruction per 4 cycles.
-#   fp64: 16 FMA lanes per clock per SIMD — the datasheet's 78.6 TFLOP/s fp64 vector — is one v_fma_f64 per 4 cycles.
-#   fp32: the datasheet's 157.3 TFLOP/s is the PACKED rate: one v_pk_fma_f32 (two FMAs per lane) per 4 cycles.  The fp32
-#         kernels here are the packed ones (two members per lane), so 4 cycles per wave-instruction is their peak too; a
-#         scalar v_fma_f32 stream reaches half the datasheet FLOP/s at best (measured 3.6 cycles per instruction).
-# What this chip SUSTAINS on a pure stream of one instruction kind (8 waves/SIMD, tools/microbench/valu_rates.hip,
-# profiles/r03/valu_rates_microbench.txt) is quoted beside the peak: the clock it holds under a dense VALU stream (~1.9-2.0
-# GHz, SQ counters) is below 2.4 GHz.  Integer / conversion / select instructions in the stream are priced like the rest.
+# Vector issue peak: 256 CUs x 4 SIMDs at 2.4 GHz.  A wave64 fp64 instruction and a PACKED fp32 instruction (two fp32 ops
+# per lane) hold their SIMD for 4 cycles — that is what the datasheet's 78.6 TFLOP/s fp64 (v_fma_f64) and 157.3 TFLOP/s fp32
+# (v_pk_fma_f32) are; a scalar fp32 or integer instruction nominally holds it for 2.  The roofline of the VALU-bound
+# kernels is the NOMINAL ISSUE TIME of their measured instruction stream (SQ counters: instructions per wave-step, and for
+# the fp32 kernels the packed share of them) divided by the measured time.  What this chip SUSTAINS on pure streams of one
+# instruction kind (8 waves/SIMD, tools/microbench/valu_rates.hip, profiles/r03/valu_rates_microbench.txt) is quoted beside
+# it: the clock it holds under a dense VALU stream is 1.96-2.03 GHz (SQ counters), not 2.4, and nothing reaches nominal.
 SIMDS = 1024
 CLOCK_HZ = 2.4e9
 VALU_CYCLES_PER_INSTR = {"f64": 4.0, "f32": 4.0}
@@ -527,17 +526,26 @@ def main():
     if valu:
         waves = -(-int(roofline["members_per_launch"]) // members_per_wave)
         rate = valu["valu_per_wave_step"] * waves / k_avg
-        issue = {"valu_wave_instr_per_wave_step": valu["valu_per_wave_step"], "members_per_wave": members_per_wave,
-                 "wave_instr_per_s": rate, "peak_wave_instr_per_s": valu_peak, "frac": rate / valu_peak,
-                 "peak_def": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction: the datasheet's 78.6 TFLOP/s fp64 "
-                             "(v_fma_f64) and 157.3 TFLOP/s fp32 (v_pk_fma_f32, the PACKED rate: the fp32 kernels are the "
-                             "packed ones)",
+        # nominal issue time of the stream: 4 cycles per fp64 or packed-fp32 wave-instruction, 2 per scalar fp32 / integer one
+        # (the datasheet's 78.6 / 157.3 TFLOP/s are v_fma_f64 and v_pk_fma_f32 at 4 cycles); the packed share of an fp32
+        # stream comes from the SQ_INSTS_VALU_FLOPS_FP32 pass (profiles/valu.json "packed_per_wave_step")
+        n_valu = valu["valu_per_wave_step"]
+        n_slow = n_valu if a.dtype == "f64" else valu.get("packed_per_wave_step", n_valu if packed else 0.0)
+        nominal_cycles = 4.0 * n_slow + 2.0 * (n_valu - n_slow)
+        nominal_s = nominal_cycles * waves / (SIMDS * CLOCK_HZ)
+        issue = {"valu_wave_instr_per_wave_step": n_valu, "members_per_wave": members_per_wave,
+                 "four_cycle_instr_per_wave_step": n_slow, "nominal_issue_cycles_per_wave_step": nominal_cycles,
+                 "wave_instr_per_s": rate, "peak_wave_instr_per_s": valu_peak * (4.0 * n_valu / nominal_cycles),
+                 "frac": nominal_s / k_avg,
+                 "peak_def": "frac = nominal issue time of the kernel's VALU stream / measured time, on 1024 SIMDs x 2.4 GHz with "
+                             "4 cycles per fp64 or packed-fp32 wave-instruction (the datasheet's 78.6 TFLOP/s v_fma_f64 and "
+                             "157.3 TFLOP/s v_pk_fma_f32) and 2 per scalar fp32 / integer one",
                  "measured_sustained_cycles_per_instr": VALU_SUSTAINED_CYCLES[a.dtype],
                  "measured_sustained_source": "profiles/r03/valu_rates_microbench.txt (pure streams, 8 waves/SIMD)",
                  "clock_GHz_under_load": valu.get("clock_GHz_under_load"),
                  "source": f"profiles/valu.json[{kkey}] (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ..., committed)"}
         if fusedlike:
-            roofline["achieved"], roofline["frac"] = rate, issue["frac"]
+            roofline["achieved"], roofline["frac"], roofline["peak"] = rate, issue["frac"], issue["peak_wave_instr_per_s"]
         roofline["fp64_issue_frac" if a.dtype == "f64" else "fp32_issue_frac"] = issue["frac"]
         roofline["valu_issue"] = issue
 

@@ -11,8 +11,10 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CITE = re.compile(r"\*\*(?P<num>[-+]?[0-9][0-9.,]*(?:e[-+]?[0-9]+)?)\*\*[^`|\n]{0,40}?\(`(?P<file>[A-Za-z0-9_./-]+\.json)"
-                  r"(?:\[(?P<key>[^\]]+)\])?(?P<path>(?:\.[A-Za-z0-9_]+)+)`(?:\s*(?P<op>[/x])\s*(?P<scale>[0-9.e+-]+))?\)")
+CITE = re.compile(r"\*\*(?P<num>[-+]?[0-9][0-9.,]*(?:e[-+]?[0-9]+)?)\*\*[^`|\n]{0,60}?\(`(?P<file>[A-Za-z0-9_./-]+\.json)"
+                  r"(?:\[(?P<key>[^\]]+)\])?(?P<path>(?:\.[A-Za-z0-9_]+)+)`(?:\s*(?P<op>[/x])\s*(?P<scale>[0-9.e+-]+))?(?=[);,])")
+# a bold number followed by a backticked .json path that the pattern above does NOT parse is a malformed citation
+LOOSE = re.compile(r"\*\*[-+]?[0-9][0-9.,e+-]*\*\*[^`|\n]{0,60}?\(`[A-Za-z0-9_./-]+\.json")
 
 
 def _resolve(name):
@@ -36,6 +38,7 @@ def test_design_md_numbers_are_in_the_files_they_cite():
         text = fh.read()
     cites = list(CITE.finditer(text))
     assert len(cites) >= 12, f"only {len(cites)} file-backed numbers found in DESIGN.md: the citation format changed?"
+    assert len(cites) == len(LOOSE.findall(text)), "a bold number cites a .json file in a form this test cannot parse"
     cache, bad = {}, []
     for m in cites:
         path = _resolve(m["file"])

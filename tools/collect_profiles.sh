@@ -34,10 +34,13 @@ timeout -k 10 400 rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OU
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_f64_1M.csv $OUT/valu.json 96 1000000 8 $OUT/pmc_sqa_step $OUT/pmc_sqb_step $OUT/pmc_sqa_fused64 $OUT/pmc_sqb_fused64 > /dev/null
 timeout -k 10 400 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_fused32 -- python3 $R/tools/pmc_workload_fused.py 4000000 f32 96 8 > $OUT/pmc_sqa_fused32.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OUT/pmc_sqb_fused32 -- python3 $R/tools/pmc_workload_fused.py 4000000 f32 96 8 > $OUT/pmc_sqb_fused32.log 2>&1
-python3 $R/tools/pmc_valu.py $OUT/sq_counters_f32_4M.csv $OUT/valu.json 96 4000000 8 $OUT/pmc_sqa_fused32 $OUT/pmc_sqb_fused32 > /dev/null
+SQC="SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_CVT"
+timeout -k 10 400 rocprofv3 --pmc $SQC --kernel-trace --output-format csv -d $OUT/pmc_sqc_fused32 -- python3 $R/tools/pmc_workload_fused.py 4000000 f32 96 8 > $OUT/pmc_sqc_fused32.log 2>&1
+python3 $R/tools/pmc_valu.py $OUT/sq_counters_f32_4M.csv $OUT/valu.json 96 4000000 8 $OUT/pmc_sqa_fused32 $OUT/pmc_sqb_fused32 $OUT/pmc_sqc_fused32 > /dev/null
 # the other kernels bench.py can be asked to price: fp32 per-step (config 5), CO2-only (config 2)
 timeout -k 10 400 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_step32 -- python3 $R/tools/pmc_workload.py 4000000 multigas f32 > $OUT/pmc_sqa_step32.log 2>&1
-python3 $R/tools/pmc_valu.py $OUT/sq_counters_step_f32_4M.csv $OUT/valu.json 1 4000000 1 $OUT/pmc_sqa_step32 > /dev/null
+timeout -k 10 400 rocprofv3 --pmc $SQC --kernel-trace --output-format csv -d $OUT/pmc_sqc_step32 -- python3 $R/tools/pmc_workload.py 4000000 multigas f32 > $OUT/pmc_sqc_step32.log 2>&1
+python3 $R/tools/pmc_valu.py $OUT/sq_counters_step_f32_4M.csv $OUT/valu.json 1 4000000 1 $OUT/pmc_sqa_step32 $OUT/pmc_sqc_step32 > /dev/null
 timeout -k 10 400 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_co2 -- python3 $R/tools/pmc_workload.py 1000000 co2 > $OUT/pmc_sqa_co2.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_co2_fused -- python3 $R/tools/pmc_workload_fused.py 1000000 f64 96 8 co2 > $OUT/pmc_sqa_co2_fused.log 2>&1
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_co2_f64_1M.csv $OUT/valu.json 96 1000000 8 $OUT/pmc_sqa_co2 $OUT/pmc_sqa_co2_fused > /dev/null

@@ -58,14 +58,24 @@ def main():
         if not valu or not waves:
             continue
         steps = 1 if m.group(1) == "step" else fused_steps
-        if m.group(1) == "tile":
-            steps, waves = tile_k, float(-(-members // 64))
         per_wave = 128 if m.group(2) == "float2" else 64            # members of one wave: packed lanes carry two each
+        if m.group(1) == "tile":
+            steps, waves = tile_k, float(-(-members // per_wave))
         tag = {"double": "f64", "float": "f32", "float2": "f32x2"}[m.group(2)]
         key = f"{m.group(1)}:{tag}:{m.group(3)},{m.group(4)},{m.group(5)}"
         rec = {"kernel": k, "valu_per_wave_step": valu / waves / steps, "members_per_wave": per_wave,
                "valu_per_member_step": valu / waves / steps / per_wave, "waves": waves, "steps_per_launch": steps,
                "dispatches": len(acc[(k, "SQ_INSTS_VALU")])}
+        # packed fp32 share of the stream (for the fp32 kernels' nominal issue time: a v_pk_* instruction holds its SIMD for 4
+        # cycles, a scalar fp32 / integer one for 2).  SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F32 count INSTRUCTIONS (a packed one
+        # once); SQ_INSTS_VALU_FLOPS_FP32 counts per-lane flops (FMA 2, packed x2): the excess over an all-scalar stream
+        # is what the packed forms add — 2 per packed FMA, 1 per packed multiply or add.
+        fl, nf, nm, na, ntr = (mean("SQ_INSTS_VALU_FLOPS_FP32"), mean("SQ_INSTS_VALU_FMA_F32"), mean("SQ_INSTS_VALU_MUL_F32"),
+                               mean("SQ_INSTS_VALU_ADD_F32"), mean("SQ_INSTS_VALU_TRANS_F32"))
+        if None not in (fl, nf, nm, na, ntr) and (2 * nf + nm + na) > 0:
+            share = max(0.0, min(1.0, (fl - (2 * nf + nm + na + ntr)) / (2 * nf + nm + na)))
+            rec["packed_per_wave_step"] = share * (nf + nm + na) / waves / steps
+            rec["fma_mul_add_trans_per_wave_step"] = [x / waves / steps for x in (nf, nm, na, ntr)]
         gui, durs = mean("GRBM_GUI_ACTIVE"), dur.get(k)
         if gui and durs:                                             # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles
             rec["clock_GHz_under_load"] = gui / 8.0 / (sum(durs) / len(durs) * 1e-6) / 1e9
