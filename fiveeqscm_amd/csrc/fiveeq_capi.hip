@@ -200,11 +200,20 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
     return FIVEEQ_OK;
 }
 
-template <typename T, bool INV>
-int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream_t st) {
+// the bin-index ring of the streamed histograms (fused_kernel<..., BINS = true>)
+struct BinRing {
+    unsigned short* ring = nullptr;
+    int ring_rows = 0;
+    double lo = 0.0, inv_w = 0.0;
+    int n_bins = 0;
+};
+
+template <typename T, bool INV, bool BINS = false>
+int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream_t st, const BinRing& br = BinRing()) {
     using P = typename LaneOf<T>::Packed;
     constexpr bool HAS_PACKED = !INV && !std::is_same<P, T>::value;     // the inverse form has no packed instantiation
-    const bool packed = HAS_PACKED && LaneOf<T>::can_pack(a);
+    // packed lanes store two 2-byte bin indices as one 4-byte word: the ring rows must be 4-byte aligned too
+    const bool packed = HAS_PACKED && LaneOf<T>::can_pack(a) && (!BINS || (((uintptr_t)br.ring) & 3) == 0);
     const int64_t blocks = member_blocks(packed ? (a.n + 1) / 2 : a.n);
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_BLOCK);
@@ -213,15 +222,15 @@ int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream
     case (p0) * 100 + (p1) * 10 + (p2):                                                                \
         if constexpr (HAS_PACKED) {                                                                    \
             if (packed) {                                                                              \
-                hipLaunchKernelGGL((fused_kernel<P, p0, p1, p2, false>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km, a.drive, \
-                                   a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj, a.T_traj,      \
-                                   a.n_rows, a.stats);                                                 \
+                hipLaunchKernelGGL((fused_kernel<P, p0, p1, p2, false, BINS>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km,  \
+                                   a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj,        \
+                                   a.T_traj, a.n_rows, a.stats, br.ring, br.ring_rows, br.lo, br.inv_w, br.n_bins);         \
                 break;                                                                                 \
             }                                                                                          \
         }                                                                                              \
-        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km, a.drive, a.n_steps, t_begin, \
-                           t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj, a.T_traj, a.n_rows,   \
-                           a.stats);                                                                   \
+        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV, BINS>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km, a.drive,   \
+                           a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj, a.T_traj, a.n_rows,    \
+                           a.stats, br.ring, br.ring_rows, br.lo, br.inv_w, br.n_bins);                \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X
@@ -272,6 +281,27 @@ int run_fused(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
     if (t_begin == t_end) return FIVEEQ_OK;
     return launch_fused<T, false>(a, t_begin, t_end, nullptr, (hipStream_t)stream);
+}
+
+template <typename T>
+int run_fused_bins(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
+                   int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats,
+                   double lo, double hi, int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
+    RunArgs<T> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
+    if (n_bins < 1 || n_bins > HIST_MAX_BINS) return fail(FIVEEQ_E_INVALID, "n_bins=%d outside 1..%d", n_bins, HIST_MAX_BINS);
+    if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) return fail(FIVEEQ_E_INVALID, "need finite lo < hi");
+    if (!bin_ring) return fail(FIVEEQ_E_INVALID, "bin_ring is NULL");
+    if (ring_rows < 1) return fail(FIVEEQ_E_INVALID, "ring_rows=%d must be >= 1", ring_rows);
+    if (((uintptr_t)bin_ring) & 1) return fail(FIVEEQ_E_INVALID, "bin_ring must be 2-byte aligned");
+    if (t_begin == t_end) return FIVEEQ_OK;
+    BinRing br;
+    br.ring = bin_ring;
+    br.ring_rows = ring_rows;
+    br.lo = lo;
+    br.inv_w = (double)n_bins / (hi - lo);
+    br.n_bins = n_bins;
+    return launch_fused<T, false, true>(a, t_begin, t_end, nullptr, (hipStream_t)stream, br);
 }
 
 template <typename T>
@@ -550,6 +580,20 @@ int fiveeq_run_fused_f32(const fiveeq_model* model, int64_t n_members, int64_t l
     return run_fused<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
                         stream);
 }
+int fiveeq_run_fused_bins_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
+                              int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
+                              double* S, double* C_traj, double* T_traj, int32_t n_rows, double* T_stats, double hist_lo,
+                              double hist_hi, int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
+    return run_fused_bins<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                                  T_stats, hist_lo, hist_hi, n_bins, bin_ring, ring_rows, stream);
+}
+int fiveeq_run_fused_bins_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
+                              int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
+                              float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, double hist_lo,
+                              double hist_hi, int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
+    return run_fused_bins<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                                 T_stats, hist_lo, hist_hi, n_bins, bin_ring, ring_rows, stream);
+}
 int fiveeq_plan_create_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
                            int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
                            float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, void** plan_out) {
@@ -781,6 +825,25 @@ int64_t fiveeq_hist_rows_chunks(int32_t n_rows, int64_t n_members) {
     if (n_rows < 1 || n_members < 1) return 0;
     const int64_t chunk = hist_chunk(n_rows, n_members);
     return (n_members + chunk - 1) / chunk;
+}
+int fiveeq_hist_bins(int32_t n_rows, int64_t n_members, int64_t ld, const uint16_t* bins, int32_t n_bins, uint64_t* hist,
+                     void* stream) {
+    if (n_rows < 0) return fail(FIVEEQ_E_INVALID, "n_rows=%d must be >= 0", n_rows);
+    if (n_members < 1 || ld < n_members)
+        return fail(FIVEEQ_E_INVALID, "n_members=%lld, ld=%lld invalid", (long long)n_members, (long long)ld);
+    if (n_bins < 1 || n_bins > fiveeq::HIST_MAX_BINS)
+        return fail(FIVEEQ_E_INVALID, "n_bins=%d outside 1..%d", n_bins, fiveeq::HIST_MAX_BINS);
+    if (n_rows == 0) return FIVEEQ_OK;
+    if (!bins || !hist) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    if (n_rows > 65535) return fail(FIVEEQ_E_INVALID, "n_rows=%d exceeds the 65535 rows of one launch", n_rows);
+    int64_t chunk = hist_chunk(n_rows, n_members);
+    chunk = (chunk + 4 * FIVEEQ_BLOCK - 1) / (4 * FIVEEQ_BLOCK) * (4 * FIVEEQ_BLOCK);      // four members per lane and load
+    const int64_t chunks = (n_members + chunk - 1) / chunk;
+    if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
+    hipLaunchKernelGGL(fiveeq::hist_bins_kernel, dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
+                       (hipStream_t)stream, n_members, ld, chunk, bins, n_bins, reinterpret_cast<unsigned long long*>(hist));
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
 }
 int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, double lo, double hi,
                          int32_t n_bins, uint64_t* hist, void* stream) {

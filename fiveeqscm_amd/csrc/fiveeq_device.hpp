@@ -668,8 +668,13 @@ __device__ __forceinline__ void wave_stats_flush(const float2v* tile /* [STAT_ST
 // 256-thread workgroups with identical buffers, profiles/r01/ab_variants.txt) and owns the same
 // members in every launch.
 // ---------------------------------------------------------------------------------
+#ifdef FIVEEQ_STEP_WAVES
+#define FIVEEQ_STEP_ATTR __attribute__((amdgpu_waves_per_eu(FIVEEQ_STEP_WAVES, FIVEEQ_STEP_WAVES)))
+#else
+#define FIVEEQ_STEP_ATTR
+#endif
 template <typename V, int P0, int P1, int P2>
-__global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
+__global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kernel(
     const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps, const int t,
     const int64_t n, const int64_t ld,
     const typename Lane<V>::S* __restrict__ r, const typename Lane<V>::S* __restrict__ q,
@@ -756,7 +761,18 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) void step_kernel(
 // INV = true: concentration-driven form.  drive[t][0..2] are target concentrations, cumE [G][ld] is
 // per-member cumulative-emission state (in/out), and C_traj receives the DIAGNOSED EMISSIONS.
 // (112 VGPRs at fp64 4+1+1 = 4 waves/SIMD; launch-bounds hints for 5 or 6 waves spill: -3 % / -16 %.)
-template <typename V, int P0, int P1, int P2, bool INV>
+// BINS = true: the streamed-histogram form.  Besides everything above, the kernel writes the histogram BIN INDEX of T of every
+// step (fiveeq_hist_rows' bin rule, bit for bit; 0xFFFF for a NaN) as one uint16 per member into a ring
+// bin_ring[ring_rows][ld] at row t mod ring_rows — 2 bytes per member-step where a ring of T rows takes w — for the
+// histogram pass (hist_bins_kernel) to count.  The pass no longer sees T, so the moments stay in the kernel (stats).
+constexpr unsigned short BIN_NAN = 0xFFFFu;
+__device__ __forceinline__ unsigned int fe_hist_bin(const double v, const double lo, const double inv_w, const int n_bins) {
+    const double pos = (v - lo) * inv_w;
+    const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
+    return v == v ? (unsigned int)b : (unsigned int)BIN_NAN;
+}
+
+template <typename V, int P0, int P1, int P2, bool INV, bool BINS = false>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps,
     const int t_begin, const int t_end, const int64_t n, const int64_t ld,
@@ -765,10 +781,13 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     typename Lane<V>::S* __restrict__ cumE /* [G][ld], INV only */,
     typename Lane<V>::S* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */,
     typename Lane<V>::S* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
-    const int n_rows, double* __restrict__ stats /* [ceil(n/64)][n_steps][4] or nullptr */) {
+    const int n_rows, double* __restrict__ stats /* [ceil(n/64)][n_steps][4] or nullptr */,
+    unsigned short* __restrict__ bin_ring /* BINS: [ring_rows][ld] */, const int ring_rows, const double hist_lo,
+    const double hist_inv_w, const int n_bins) {
     using L = Layout<P0, P1, P2>;
     using T = typename Lane<V>::S;
     constexpr int W = Lane<V>::W;                 // members per lane
+    static_assert(!(INV && BINS), "no streamed histograms in the concentration-driven form");
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
     __shared__ V stat_tile[FIVEEQ_BLOCK / 64][STAT_STEPS * STAT_ROW];
     __shared__ KModel<T> km_s;
@@ -820,6 +839,19 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
                         for (int g = 0; g < L::G; ++g) store_lane(c + g * ld, Cv[g], full);
                     }
                     if (T_traj != nullptr) store_lane(T_traj + (int64_t)row * ld + m, Tn, full);
+                }
+            }
+            if constexpr (BINS) {
+                if (active) {
+                    unsigned short* o = bin_ring + (int64_t)((tc + k) % ring_rows) * ld + m;     // scalar row offset
+                    if constexpr (W == 1) {
+                        *o = (unsigned short)fe_hist_bin((double)Tn, hist_lo, hist_inv_w, n_bins);
+                    } else {
+                        const unsigned int b0 = fe_hist_bin((double)Tn.x, hist_lo, hist_inv_w, n_bins);
+                        const unsigned int b1 = fe_hist_bin((double)Tn.y, hist_lo, hist_inv_w, n_bins);
+                        if (full) *reinterpret_cast<unsigned int*>(o) = b0 | (b1 << 16);    // both members: one 4-byte store
+                        else *o = (unsigned short)b0;
+                    }
                 }
             }
             if (wave_live) {
@@ -1163,6 +1195,44 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
         double* o = moments + (row * gridDim.x + blockIdx.x) * 4;
         o[0] = a, o[1] = b, o[2] = c, o[3] = d;
     }
+    unsigned long long* out = hist + row * n_bins;
+    for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) {
+        const unsigned int c = h[b];
+        if (c) atomicAdd(&out[b], (unsigned long long)c);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 4b — the pass of the bin-index ring: hist[row][b] += #members whose stored bin index is b (BIN_NAN skipped).
+// Same grid shape and LDS privatisation as hist_rows_kernel; reads 2 bytes per member and row, four members per 8-byte load.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_bins_kernel(const int64_t n, const int64_t ld, const int64_t chunk,
+                                                                 const unsigned short* __restrict__ rows, const int n_bins,
+                                                                 unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int h[HIST_MAX_BINS];
+    for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) h[b] = 0u;
+    __syncthreads();
+    const int64_t row = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * chunk;          // chunk is a multiple of 4 * FIVEEQ_BLOCK (host)
+    const int64_t m1 = min(m0 + chunk, n);
+    const unsigned short* x = rows + row * ld;
+    auto count = [&](const unsigned int b) {
+        if (b < (unsigned int)n_bins) atomicAdd(&h[b], 1u);
+    };
+    const bool wide = ((((uintptr_t)x) | ((uintptr_t)(ld * 2))) & 7) == 0;      // rows 8-byte aligned: 4 members per load
+    int64_t m = m0 + (int64_t)threadIdx.x * 4;
+    if (wide) {
+        for (; m + 3 < m1; m += 4 * FIVEEQ_BLOCK) {
+            const uint2 v = *reinterpret_cast<const uint2*>(x + m);
+            count(v.x & 0xffffu);
+            count(v.x >> 16);
+            count(v.y & 0xffffu);
+            count(v.y >> 16);
+        }
+    }
+    for (; m < m1; m += 4 * FIVEEQ_BLOCK)                     // unaligned rows, and the ragged tail of the last chunk
+        for (int j = 0; j < 4 && m + j < m1; ++j) count(x[m + j]);
+    __syncthreads();
     unsigned long long* out = hist + row * n_bins;
     for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) {
         const unsigned int c = h[b];

@@ -56,7 +56,7 @@ class EnsembleEngine:
 
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
                  device=None, store_trajectory=True, output_steps=None, store_concentrations=True,
-                 collect_stats=False, hist=None, hist_ring_steps="auto",
+                 collect_stats=False, hist=None, hist_ring_steps="auto", hist_ring="bins",
                  concentration_driven=False, chunk_members="auto", R0=None, S0=None, lib_path=None):
         """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
         stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
@@ -66,10 +66,13 @@ class EnsembleEngine:
         hist=(lo, hi, n_bins): allocate `T_hist` [n_steps, n_bins] (int64), the fixed-bin histogram of T of
         EVERY step, for all-timestep percentiles (distributed.histogram_percentiles) without a stored
         trajectory.  Three ways to fill it, same counts bit for bit:
-          run(mode="fused")    streams it: the fused kernel parks T of `hist_ring_steps` steps at a time in a two-slot
-                               ring [2, S, N] ("auto": what 8 GB hold, at most 128 steps; 6.4 GB for 12.5M fp32 members
-                               at S = 64) and the histogram kernel drains one slot on a second HIP stream while the next
-                               is computed, returning the per-step moments with it (no in-kernel statistics);
+          run(mode="fused")    streams it, `hist_ring_steps` steps at a time through a two-slot ring that a histogram kernel
+                               drains on a second HIP stream while the next slot is computed.  hist_ring="bins" (default):
+                               the fused kernel writes each member's BIN INDEX (uint16: 2 bytes per member-step; 3.2 GB for
+                               12.5M members at S = 64) and keeps the statistics in the kernel; hist_ring="T": it parks T
+                               itself (4 or 8 bytes) and the pass returns the per-step moments with the counts (no in-kernel
+                               statistics; T rows only, no stored concentrations).  "auto" ring length: what 8 GB of T
+                               ring would hold, at most 128 steps;
           run(mode="tiled")    accumulates it INSIDE the kernel's time loop (LDS-privatised, no scratch memory);
           run(mode="per_step") histograms each step's T row right behind the step kernel (one scratch row).
         concentration_driven: inverse mode — `emissions` holds the TARGET concentrations [n_steps, G]
@@ -160,7 +163,11 @@ class EnsembleEngine:
             # where the streamed pipeline's histogram pass runs: "side" = a second HIP stream beside the next chunk's fused
             # kernel, "same" = behind each chunk on the caller's stream (see _run_fused_streamed_hist)
             self.hist_pass_stream = os.environ.get("FIVEEQ_HIST_PASS_STREAM", "side")
+            if hist_ring not in ("bins", "T"):
+                raise ValueError("hist_ring must be 'bins' or 'T'")
+            self.hist_ring = hist_ring
             self._ring = None            # allocated by the first streamed-histogram run
+            self._bins = None
         if chunk_members == "auto":
             chunk_members = self.auto_chunk(N, SP, G, dtype)
         self.chunk_members = int(chunk_members or 0) // 256 * 256
@@ -353,7 +360,7 @@ class EnsembleEngine:
         if self.T_hist is not None and mode in ("graph", "ksteps"):
             raise ValueError(f"mode {mode!r} does not fill T_hist: use 'fused', 'tiled' or 'per_step' with hist=")
         with torch.cuda.device(self.device):
-            if not (mode == "fused" and self.T_hist is not None and not self.concentration_driven):
+            if not (mode == "fused" and self.T_hist is not None and not self.concentration_driven and self.hist_ring == "T"):
                 self._wave_stats()
                 # these launches write per-wave records: moments an earlier streamed pass left for the same steps are stale
                 self._step_sums_valid[int(t_begin):t_end] = False
@@ -366,6 +373,8 @@ class EnsembleEngine:
                 rc = _capi.OK
                 for m0, n in self._chunks():                      # chunk-major: see chunk_members
                     rc = rc or fn(*self._run_args(t_begin, t_end, m0, n), self._stream(stream))
+            elif mode == "fused" and self.T_hist is not None and self.hist_ring == "bins":
+                rc = self._run_fused_bin_ring(t_begin, t_end, stream)
             elif mode == "fused" and self.T_hist is not None:
                 rc = self._run_fused_streamed_hist(t_begin, t_end, stream)
             elif mode == "fused":
@@ -438,6 +447,52 @@ class EnsembleEngine:
                             self.T[stored[tt], m0:m0 + n].copy_(buf[tt % S, m0:m0 + n])
                 t = t1
         return _capi.OK
+
+    def _bin_ring(self):
+        """Two-slot ring [2, S, N] of uint16 bin indices for the streamed histograms (hist_ring='bins')."""
+        N, S, dev = self.n_members, max(1, min(int(self.hist_ring_steps), self.n_steps)), self.device
+        ring = self._bins
+        if ring is None or ring["S"] != S:
+            torch.cuda.synchronize(dev)
+            self._bins = None
+            self._bins = ring = {"S": S, "buf": torch.empty((2, S, N), dtype=torch.int16, device=dev),
+                                 "side": torch.cuda.Stream(device=dev), "drained": [torch.cuda.Event(), torch.cuda.Event()]}
+        return ring
+
+    def _run_fused_bin_ring(self, t_begin, t_end, stream):
+        """mode='fused' with hist= and hist_ring='bins': chunks of S = hist_ring_steps steps.  Stream A (the caller's) runs
+        fiveeq_run_fused_bins_* for chunk i: the ordinary fused kernel — the engine's own drive table, stored C/T rows and
+        per-wave statistics exactly as in a plain fused run — that also writes every member's histogram bin of every step
+        into ring slot i % 2 (row t mod S, one uint16 per member).  Stream B waits for the chunk and counts the slot's rows into
+        T_hist[t:t+S] (fiveeq_hist_bins); A reuses a slot only after B has drained it.  Half (fp32) or a quarter (fp64) of
+        the T ring's traffic in both directions; the moments come from the kernel's wave records."""
+        N, dev = self.n_members, self.device
+        ring = self._bin_ring()
+        S = ring["S"]
+        main = stream if stream is not None else torch.cuda.current_stream(dev)
+        side = main if self.hist_pass_stream == "same" else ring["side"]
+        side.wait_stream(main)
+        fused = getattr(self.lib, f"fiveeq_run_fused_bins_{self._sfx}")
+        lo_h, hi_h, nb = self.hist_spec
+        used = [False, False]
+        rc, t, i = _capi.OK, int(t_begin), 0
+        while t < t_end and rc == _capi.OK:
+            t1 = min(t_end, (t // S + 1) * S)              # chunks end on multiples of S: row = t mod S never wraps
+            slot = i % 2
+            buf = ring["buf"][slot]
+            if used[slot]:
+                main.wait_event(ring["drained"][slot])
+            rc = fused(*self._run_args(t, t1), lo_h, hi_h, nb, self._ptr(buf), S, ctypes.c_void_p(main.cuda_stream))
+            side.wait_stream(main)
+            if rc == _capi.OK:
+                with torch.cuda.stream(side):
+                    rc = self.lib.fiveeq_hist_bins(t1 - t, N, N, self._ptr(buf[t % S:]), nb, self._ptr(self.T_hist[t:t1]),
+                                                   ctypes.c_void_p(side.cuda_stream))
+                ring["drained"][slot].record(side)
+                used[slot] = True
+            t, i = t1, i + 1
+        main.wait_stream(side)
+        return rc
 
     def _run_fused_streamed_hist(self, t_begin, t_end, stream):
         """mode='fused' with hist=: chunks of S = hist_ring_steps steps.  Stream A (the caller's) runs the fused kernel
@@ -606,6 +661,8 @@ class EnsembleEngine:
         extra = (32.0 / 64.0) if self.collect_stats else 0.0          # one 32-B stats record per wave
         ring = 2.0 * w if (self.T_hist is not None and mode in ("fused", "per_step")) else 0.0
         if mode == "fused" and self.T_hist is not None:
+            if self.hist_ring == "bins":                       # 2 B written + 2 B read per member-step; wave records stay
+                ring = 4.0 + extra
             return w * (out + (2 * SP + 3 * G + 6) / max(1, min(self.hist_ring_steps, self.n_steps))) + ring
         if mode == "fused":
             return w * (out + (2 * SP + 3 * G + 6) / self.n_steps) + extra

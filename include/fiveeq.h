@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   5
+#define FIVEEQ_ABI_VERSION   6
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
@@ -263,6 +263,29 @@ int fiveeq_hist_rows_stats_f64(int32_t n_rows, int64_t n_members, int64_t ld, co
 int fiveeq_hist_rows_stats_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
                                double lo, double hi, int32_t n_bins, uint64_t *hist, double *moments, void *stream);
 int64_t fiveeq_hist_rows_chunks(int32_t n_rows, int64_t n_members);
+
+/* STREAMED HISTOGRAMS through a ring of BIN INDICES (round 3).  fiveeq_run_fused_bins_* is
+ * fiveeq_run_fused_* (same arguments, same results, C_traj / T_traj / T_stats as there) that ALSO writes, for every step t of
+ * the span and every member m, the histogram bin of T(t, m) — the rule of fiveeq_hist_rows_* with (hist_lo, hist_hi, n_bins),
+ * bit for bit; 0xFFFF for a NaN — as one uint16 into bin_ring dev [ring_rows][ld] at row t mod ring_rows: 2 bytes per
+ * member-step where a ring of T rows takes 4 or 8.  fiveeq_hist_bins then counts rows of such indices into
+ * hist dev [n_rows][n_bins] uint64 (ACCUMULATED INTO).  The caller runs spans of at most ring_rows steps and drains the
+ * ring between them (EnsembleEngine does, on a second stream).  The pass does not see T: per-step moments, if wanted,
+ * come from T_stats. */
+int fiveeq_run_fused_bins_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                              const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                              const double *r, const double *q, double *R, double *S,
+                              double *C_traj, double *T_traj, int32_t n_rows, double *T_stats,
+                              double hist_lo, double hist_hi, int32_t n_bins,
+                              uint16_t *bin_ring, int32_t ring_rows, void *stream);
+int fiveeq_run_fused_bins_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                              const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                              const float *r, const float *q, float *R, float *S,
+                              float *C_traj, float *T_traj, int32_t n_rows, double *T_stats,
+                              double hist_lo, double hist_hi, int32_t n_bins,
+                              uint16_t *bin_ring, int32_t ring_rows, void *stream);
+int fiveeq_hist_bins(int32_t n_rows, int64_t n_members, int64_t ld, const uint16_t *bins, int32_t n_bins,
+                     uint64_t *hist, void *stream);
 
 /* new — shard-computable Latin hypercube: out[k][i] = u_{dim0+k}(m0 + i),
  * 0 <= i < n_members, 0 <= k < n_dim, for a design over n_total members:

@@ -442,8 +442,9 @@ def test_reset_and_reload_clear_the_run_accumulators(gpu):
     N, n_steps = 3000, 40
     p = prm.sample_ensemble(prm.default_params("multigas"), N)
     E = emi.rcp_like_emissions(750, 3)[240:240 + n_steps]
-    eng = _engine(p, N, E, store_concentrations=False, collect_stats=True, hist=(-1.0, 4.0, 256), hist_ring_steps=8)
-    eng.run(mode="fused")                                                # streamed: moments come from the histogram pass
+    eng = _engine(p, N, E, store_concentrations=False, collect_stats=True, hist=(-1.0, 4.0, 256), hist_ring_steps=8,
+                  hist_ring="T")
+    eng.run(mode="fused")                                                # streamed T ring: moments come from the histogram pass
     torch.cuda.synchronize()
     hist1, sums1 = eng.T_hist.clone(), eng.stats_sums().clone()
     assert eng._step_sums_valid.all() and hist1.sum(1).tolist() == [N] * n_steps
@@ -771,7 +772,8 @@ def test_randomized_launch_shapes_and_histogram_specs(gpu):
         k_tile = int(rng.integers(0, 9))
         for mode, k in (("tiled", k_tile), ("fused", None), ("per_step", None), ("ksteps", int(rng.integers(1, 20)))):
             eng = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=True,
-                          hist=None if mode == "ksteps" else (lo, hi, nb), hist_ring_steps=int(rng.integers(1, 12)))
+                          hist=None if mode == "ksteps" else (lo, hi, nb), hist_ring_steps=int(rng.integers(1, 12)),
+                          hist_ring=("bins", "T")[case % 2])
             eng.load_state_dict(state)
             k_use = min(k, eng.tile_steps()) if mode == "tiled" else k
             eng.run(t0, t1, mode=mode, k_steps=k_use)
@@ -1247,3 +1249,34 @@ def test_tiled_kernel_lds_limit_is_set_once_per_instantiation(gpu):
     torch.cuda.synchronize()
     assert lib.fiveeq_tile_attr_calls() == counts[-1]
     small.close()
+
+
+def test_bin_index_ring_equals_the_T_ring_and_keeps_stored_concentrations(gpu):
+    """The default streamed form writes 2-byte bin indices from inside the fused kernel: its T_hist must equal the T ring's
+    and the histogram of stored rows bit for bit (same bin rule), the model results must not notice it, the moments come
+    from the kernel's wave records — and, unlike the T ring, it coexists with stored C rows.  Ragged sizes (the last packed
+    lane holds one member; rows that are not 8-byte aligned take the pass's narrow path), NaN-free edge bins in use."""
+    rng = np.random.default_rng(3)
+    for N, td in ((1, torch.float64), (2, torch.float32), (1001, torch.float64), (1001, torch.float32), (4098, torch.float32),
+                  (70_000, torch.float32), (70_001, torch.float64)):
+        n_steps = 41
+        p = prm.sample_ensemble(prm.default_params("multigas"), N, seed=N)
+        E = emi.rcp_like_emissions(750, 3)[270:270 + n_steps]
+        lo, hi, nb = 0.2, 1.4, int(rng.choice([7, 512, 4096]))          # tight range: both edge bins collect outliers
+        a = _engine(p, N, E, dtype=td, collect_stats=True, hist=(lo, hi, nb), hist_ring_steps=int(rng.integers(1, 9)))
+        a.run(mode="fused")
+        b = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=True, hist=(lo, hi, nb), hist_ring="T",
+                    hist_ring_steps=5)
+        b.run(mode="fused")
+        ref = _engine(p, N, E, dtype=td, collect_stats=True)
+        ref.run(mode="fused")
+        torch.cuda.synchronize()
+        assert a.hist_ring == "bins" and a.C is not None
+        assert torch.equal(a.T_hist, b.T_hist) and torch.equal(a.T_hist, ref.T_histogram(lo, hi, nb)), (N, td, nb)
+        assert a.T_hist.sum(1).tolist() == [N] * n_steps
+        assert N < 1000 or (int(a.T_hist[:, 0].sum()) > 0 and int(a.T_hist[:, -1].sum()) > 0)      # both edge bins in use
+        for name in ("C", "T", "R", "S", "T_stats"):
+            assert torch.equal(getattr(a, name), getattr(ref, name)), (N, td, name)
+        assert torch.equal(a.stats_sums(), ref.stats_sums()) and not a._step_sums_valid.any()
+        for e in (a, b, ref):
+            e.close()

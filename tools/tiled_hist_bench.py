@@ -65,13 +65,16 @@ def main():
             print(f"  tiled K={kk:2d} hist {nb:4d} bins        {t / a.steps * 1e6:9.2f} us/step  {t / t_fused - 1:+.1%} vs fused"
                   f"   A_tile = {eng.bytes_per_member_step('tiled', kk):.1f} B/member-step")
         assert eng.T_hist.sum(1).min().item() == N
-        for S in (16, 32, 64, 128):
-            for where in ("side", "same"):
-                eng.hist_ring_steps, eng._ring, eng.hist_pass_stream = S, None, where
-                t = timed(eng, a.reps, mode="fused")
-                print(f"  fused + streamed hist {nb:4d} bins, ring 2x{S:2d} steps, pass on the {where} stream {t / a.steps * 1e6:9.2f} "
-                      f"us/step  {t / t_fused - 1:+.1%} vs fused   ring {2 * S * N * (4 if a.dtype == 'f32' else 8) / 1e9:.2f} GB")
-        eng.hist_pass_stream = "side"
+        for kind in ("bins", "T"):
+            for S in (16, 32, 64, 128):
+                for where in (("side", "same") if S in (32, 64) else ("side",)):
+                    eng.hist_ring, eng.hist_ring_steps, eng._ring, eng._bins, eng.hist_pass_stream = kind, S, None, None, where
+                    t = timed(eng, a.reps, mode="fused")
+                    wb = 2 if kind == "bins" else (4 if a.dtype == "f32" else 8)
+                    print(f"  fused + streamed hist {nb:4d} bins, {'bin-index' if kind == 'bins' else 'T'} ring 2x{S:3d} steps, pass on "
+                          f"the {where} stream {t / a.steps * 1e6:9.2f} us/step  {t / t_fused - 1:+.1%} vs fused   ring "
+                          f"{2 * S * N * wb / 1e9:.2f} GB")
+        eng.hist_pass_stream, eng.hist_ring = "side", "bins"
         assert eng.T_hist.sum(1).min().item() == N
         del eng
     # the north-star per-step form with the same histograms: S step launches (enqueued from C) store T into a ring strip,
