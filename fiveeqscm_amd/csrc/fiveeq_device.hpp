@@ -576,6 +576,29 @@ __device__ __forceinline__ void store_lane(float* p, float2v v, bool full) {
 // ---------------------------------------------------------------------------------
 constexpr int STAT_STEPS = 8;
 constexpr int STAT_ROW = 65;
+// min / max as ONE instruction.  fmin()/fmax() on a value the compiler cannot prove canonical get a v_max(x, x) in front
+// (sNaN quieting) — 56 of them in the fused kernel's statistics flush; the values here come out of the model's FMAs.  A NaN
+// operand is ignored by v_min / v_max like by fmin / fmax (IEEE mode), so the record of a wave with a NaN member is the same.
+__device__ __forceinline__ float fe_min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fe_max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double fe_min_raw(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double fe_max_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 template <typename T>
 __device__ __forceinline__ void wave_stats_flush(const T* tile /* [STAT_STEPS][STAT_ROW] */, const int count,
@@ -584,16 +607,33 @@ __device__ __forceinline__ void wave_stats_flush(const T* tile /* [STAT_STEPS][S
     const int lane = threadIdx.x & 63;
     const int j = lane & (STAT_STEPS - 1), p = lane >> 3;
     const double inf = __builtin_inf();
-    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;
+    double s1 = 0.0, s2 = 0.0, mn, mx;
+    if (n_valid >= 64) {                                   // a full wave (all but the ensemble's last): no per-value tests, and
+        T lo_v = tile[j * STAT_ROW + p * 8], hi_v = lo_v;  // min / max in the values' own precision (exact), converted once
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = p * 8 + i;
-        const double v = (double)tile[j * STAT_ROW + idx];
-        if (idx < n_valid) {
+        for (int i = 0; i < 8; ++i) {
+            const T t = tile[j * STAT_ROW + p * 8 + i];
+            const double v = (double)t;
             s1 += v;
             s2 = __builtin_fma(v, v, s2);
-            mn = fmin(mn, v);
-            mx = fmax(mx, v);
+            lo_v = fe_min_raw(lo_v, t);
+            hi_v = fe_max_raw(hi_v, t);
+        }
+        mn = (double)lo_v;
+        mx = (double)hi_v;
+    } else {
+        mn = inf;
+        mx = -inf;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = p * 8 + i;
+            const double v = (double)tile[j * STAT_ROW + idx];
+            if (idx < n_valid) {
+                s1 += v;
+                s2 = __builtin_fma(v, v, s2);
+                mn = fmin(mn, v);
+                mx = fmax(mx, v);
+            }
         }
     }
 #pragma unroll
@@ -622,19 +662,39 @@ __device__ __forceinline__ void wave_stats_flush(const float2v* tile /* [STAT_ST
     const int lane = threadIdx.x & 63;
     const int j = lane & (STAT_STEPS - 1), p = lane >> 3;
     const double inf = __builtin_inf();
-    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;
+    double s1 = 0.0, s2 = 0.0, mn, mx;
+    if (n_valid >= 128) {                                  // a full wave: same order of the sums as below, no per-value tests
+        const float2v first = tile[j * STAT_ROW + p * 8];
+        float lo_v = first.x, hi_v = first.x;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = p * 8 + i;
-        const float2v v2 = tile[j * STAT_ROW + idx];
+        for (int i = 0; i < 8; ++i) {
+            const float2v v2 = tile[j * STAT_ROW + p * 8 + i];
+            const double x = (double)v2.x, y = (double)v2.y;
+            s1 += x;
+            s2 = __builtin_fma(x, x, s2);
+            s1 += y;
+            s2 = __builtin_fma(y, y, s2);
+            lo_v = fe_min_raw(fe_min_raw(lo_v, v2.x), v2.y);
+            hi_v = fe_max_raw(fe_max_raw(hi_v, v2.x), v2.y);
+        }
+        mn = (double)lo_v;
+        mx = (double)hi_v;
+    } else {
+        mn = inf;
+        mx = -inf;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const double v = (double)(c == 0 ? v2.x : v2.y);
-            if (2 * idx + c < n_valid) {
-                s1 += v;
-                s2 = __builtin_fma(v, v, s2);
-                mn = fmin(mn, v);
-                mx = fmax(mx, v);
+        for (int i = 0; i < 8; ++i) {
+            const int idx = p * 8 + i;
+            const float2v v2 = tile[j * STAT_ROW + idx];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double v = (double)(c == 0 ? v2.x : v2.y);
+                if (2 * idx + c < n_valid) {
+                    s1 += v;
+                    s2 = __builtin_fma(v, v, s2);
+                    mn = fmin(mn, v);
+                    mx = fmax(mx, v);
+                }
             }
         }
     }
