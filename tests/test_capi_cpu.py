@@ -218,3 +218,26 @@ def test_abi_v5_host_side_guards():
     assert np.array_equal(u, got)
     scaled = u * n
     assert np.all(scaled - np.floor(scaled) > 0) and np.all(np.floor(scaled) < n)
+
+
+def test_abi_v6_bin_ring_entry_points_validate_on_the_host():
+    """fiveeq_run_fused_bins_* / fiveeq_hist_bins: bad arguments return on the host, nothing is launched."""
+    lib = _capi.load()
+    m = prm.make_model(prm.default_params("multigas"))
+    p = ctypes.c_void_p(0x1000)
+    common = (ctypes.byref(m), 8, 8, p, 4, 0, 4, p, p, p, p, None, None, 0, None)
+    bins = lambda lo, hi, nb, ring, rows: lib.fiveeq_run_fused_bins_f64(*common, lo, hi, nb, ring, rows, None)   # noqa: E731
+    assert bins(0.0, 1.0, 0, p, 4) == _capi.E_INVALID and b"n_bins" in lib.fiveeq_last_error()
+    assert bins(0.0, 1.0, 4097, p, 4) == _capi.E_INVALID
+    assert bins(1.0, 1.0, 16, p, 4) == _capi.E_INVALID and b"lo < hi" in lib.fiveeq_last_error()
+    assert bins(0.0, float("nan"), 16, p, 4) == _capi.E_INVALID
+    assert bins(0.0, 1.0, 16, None, 4) == _capi.E_INVALID and b"bin_ring" in lib.fiveeq_last_error()
+    assert bins(0.0, 1.0, 16, p, 0) == _capi.E_INVALID and b"ring_rows" in lib.fiveeq_last_error()
+    assert bins(0.0, 1.0, 16, ctypes.c_void_p(0x1001), 4) == _capi.E_INVALID and b"aligned" in lib.fiveeq_last_error()
+    empty = (ctypes.byref(m), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, None)
+    assert lib.fiveeq_run_fused_bins_f32(*empty, 0.0, 1.0, 16, p, 4, None) == _capi.OK           # empty span: nothing to do
+    count = lambda rows, n, ld, b, nb, h: lib.fiveeq_hist_bins(rows, n, ld, b, nb, h, None)       # noqa: E731
+    assert count(-1, 8, 8, p, 16, p) == _capi.E_INVALID and count(2, 0, 8, p, 16, p) == _capi.E_INVALID
+    assert count(2, 9, 8, p, 16, p) == _capi.E_INVALID and count(2, 8, 8, p, 0, p) == _capi.E_INVALID
+    assert count(2, 8, 8, None, 16, p) == _capi.E_INVALID and count(2, 8, 8, p, 16, None) == _capi.E_INVALID
+    assert count(70000, 8, 8, p, 16, p) == _capi.E_INVALID and count(0, 8, 8, None, 16, None) == _capi.OK
