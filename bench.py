@@ -103,13 +103,13 @@ def parse():
     return ap.parse_args()
 
 
-def run_steps(eng, t0, k, mode, k_steps):
+def run_steps(eng, t0, k, mode, k_steps, join=True):
     """Advance k model timesteps starting at scenario index t0 (cycling); returns the next index."""
     n = eng.n_steps
     t = t0 % n
     while k > 0:
         seg = min(k, n - t)
-        eng.run(t, t + seg, mode=mode, k_steps=k_steps)
+        eng.run(t, t + seg, mode=mode, k_steps=k_steps, join=join)
         k -= seg
         t = (t + seg) % n
     return t
@@ -383,17 +383,30 @@ def main():
         torch.cuda.synchronize(dev)
         barrier()
         torch.cuda.synchronize(dev)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(repeats + 1)]
+        # The per-step mode may run each timestep as several kernels on their own streams (engine.per_step_streams): a mark
+        # is then one event PER STREAM, the blocks are not joined in between (a join is two cross-stream hops, ~20 us, that a
+        # continuous run does not have), and a block lasts as long as its slowest stream takes from mark to mark.
+        lanes = eng.per_step_stream_list() if a.mode == "per_step" else [torch.cuda.current_stream(dev)]
+
+        def mark():
+            evs = [torch.cuda.Event(enable_timing=True) for _ in lanes]
+            for ev, lane in zip(evs, lanes):
+                ev.record(lane)
+            return evs
+
         t0 = time.perf_counter()
-        marks[0].record()
+        marks = [mark()]
         for i in range(repeats):
-            t_idx = run_steps(eng, t_idx, a.steps, a.mode, k_steps)
-            marks[i + 1].record()
-        while not marks[-1].query():
+            t_idx = run_steps(eng, t_idx, a.steps, a.mode, k_steps, join=False)
+            marks.append(mark())
+        eng.join()
+        done = torch.cuda.Event()
+        done.record()
+        while not done.query():
             pass
         wall_all = time.perf_counter() - t0
         torch.cuda.synchronize(dev)
-        blocks = [marks[i].elapsed_time(marks[i + 1]) * 1e-3 for i in range(repeats)]
+        blocks = [max(e0.elapsed_time(e1) for e0, e1 in zip(marks[i], marks[i + 1])) * 1e-3 for i in range(repeats)]
     blocks = max_over_ranks(blocks)                              # per block: the slowest rank
     elapsed = float(np.median(blocks))
     value = n_total * a.steps / elapsed
@@ -405,7 +418,8 @@ def main():
               max_over_ranks([wall_all])[0] / (a.steps * repeats) * 1e3,
               "clocked": ("one K-step block on the wall clock (it is longer than --min-timed-ms)" if repeats == 1 else
                           f"{repeats} K-step blocks enqueued back to back after one barrier + device sync; block = HIP event "
-                          "to HIP event on the launch stream; MAX over ranks per block, then the median block")}
+                          "to HIP event on the launch stream (the slowest of the launch streams when a timestep is several "
+                          "concurrent launches); MAX over ranks per block, then the median block")}
     if repeats > 1 and eng.T is not None:
         # the repeated blocks cycled through the scenario and overwrote stored rows with later passes: re-run the
         # W + K steps of the first block from the initial state (untimed) so that the summary below is taken on the rows
@@ -450,18 +464,28 @@ def main():
     fusedlike = a.mode in ("fused", "ksteps", "tiled") or (a.mode == "auto" and eng.auto_k_steps() > 1)
     if not fusedlike:
         A = eng.bytes_per_member_step("per_step")
-        n_launch = len(eng._chunks())          # > 1 when the engine schedules chunk-major (large ensembles)
+        # One timestep = n_seq member chunks one after the other (chunk-major schedule of large ensembles) x `conc` parts of
+        # a chunk side by side on their own HIP streams (engine.per_step_streams; graph replay keeps one stream).  The
+        # launches of the `conc` parts overlap fully — each stream issues its next kernel the moment its last one ends — so
+        # the period of a chunk's step is also what each of those kernels lasts: `avg_launch_us` below is that period, the
+        # figure rocprofv3 --kernel-trace reports as the kernel's average duration, and the chip moves `conc` launches'
+        # bytes in it.
+        layout = eng.per_step_launches() if a.mode == "per_step" else [(m0_, n_, 0) for m0_, n_ in eng._chunks()]
+        conc = 1 + max(si for _, _, si in layout)
+        n_seq = len(layout) // conc
+        n_launch = len(layout)
         members_per_launch = n_local / n_launch
         per_batch = 100
-        samples = event_timed(eng, lambda t0_, t1_: eng.run(t0_, t1_), t_idx, n_scen, per_batch, a.kernel_batches)
-        samples = samples / (per_batch * n_launch)
+        samples = event_timed(eng, lambda t0_, t1_: eng.run(t0_, t1_, mode=a.mode if a.mode == "graph" else "per_step"),
+                              t_idx, n_scen, per_batch, a.kernel_batches)
+        samples = samples / (per_batch * n_seq)
         k_avg = float(samples.mean())
-        achieved = A * members_per_launch / k_avg / 1e9
+        achieved = A * members_per_launch * conc / k_avg / 1e9
         tkey = f"{a.workload}:{a.dtype}:{per_gpu}"
         traffic = (load_profile_json("traffic.json", tkey) or {}).get("hbm_bytes_per_launch")
-        resident = wbytes * (eng.sum_pools + 2 + 3 * G + 2) * members_per_launch          # state + parameter rows of a launch
+        resident = wbytes * (eng.sum_pools + 2 + 3 * G + 2) * members_per_launch * conc   # state + parameter rows of a chunk
         if resident <= 0.8 * (256 << 20):
-            note = (f"achieved = algorithmic bytes / kernel time.  At {int(members_per_launch)} members per launch the "
+            note = (f"achieved = algorithmic bytes / kernel time.  At {int(members_per_launch * conc)} members per step the "
                     f"{resident / 1e6:.0f} MB of state + parameters stay in the 256 MiB Infinity Cache between launches, so "
                     "this is HBM-peak-priced algorithmic traffic, not bytes that crossed HBM; `hbm_resident` is the same "
                     "kernel with nothing cached.")
@@ -469,7 +493,10 @@ def main():
             note = (f"achieved = algorithmic bytes / kernel time.  {resident / 1e6:.0f} MB of state + parameters per launch "
                     "against a 256 MiB Infinity Cache: most of these bytes cross HBM every launch"
                     + (" (chunk-major schedule: one member chunk at a time stays cached between its launches)."
-                       if n_launch > 1 else "."))
+                       if n_seq > 1 else "."))
+        if conc > 1:
+            note += (f"  {conc} launches of {int(members_per_launch)} members each run side by side on their own streams: "
+                     f"achieved = {conc} x algorithmic bytes per launch / the launch duration.")
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": (f"profiles/traffic.json[{tkey}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
@@ -478,7 +505,9 @@ def main():
                     if traffic is not None else None,
                     "kernel": f"fiveeq::step_kernel<{lname},{pools3}>",
                     "algorithmic_bytes_per_member_step": A, "members_per_launch": members_per_launch,
+                    "concurrent_launches": conc, "sequential_chunks_per_step": n_seq,
                     "algorithmic_bytes_per_launch": A * members_per_launch,
+                    "achieved_per_launch": A * members_per_launch / k_avg / 1e9,
                     "avg_launch_us": k_avg * 1e6, "min_launch_us": float(samples.min()) * 1e6,
                     "launches_timed": int(samples.size) * per_batch * n_launch, "note": note}
         kkey = f"step:{vtag}:{pools3}"
@@ -524,7 +553,7 @@ def main():
     # tools/collect_profiles.sh with rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ...), times the waves this bench ran
     valu = load_profile_json("valu.json", kkey)
     if valu:
-        waves = -(-int(roofline["members_per_launch"]) // members_per_wave)
+        waves = -(-int(roofline["members_per_launch"] * roofline.get("concurrent_launches", 1)) // members_per_wave)
         rate = valu["valu_per_wave_step"] * waves / k_avg
         # nominal issue time of the stream: 4 cycles per fp64 or packed-fp32 wave-instruction, 2 per scalar fp32 / integer one
         # (the datasheet's 78.6 / 157.3 TFLOP/s are v_fma_f64 and v_pk_fma_f32 at 4 cycles); the packed share of an fp32
@@ -594,7 +623,8 @@ def main():
         roofline["hbm_resident"] = {"members": n_big, "state_and_parameter_bytes": resident,
                                     "x_infinity_cache": resident / (256 << 20), "avg_launch_us": float(sm.mean()) * 1e6,
                                     "achieved": ach, "frac": ach / HBM_PEAK_GBS, "chunk_major": False,
-                                    "algorithmic_bytes_per_launch": Ab * n_big}
+                                    "concurrent_launches": big.per_step_streams,
+                                    "algorithmic_bytes_per_step": Ab * n_big}
         roofline["hbm_resident_frac"] = ach / HBM_PEAK_GBS
         big.close()
         del big, pb

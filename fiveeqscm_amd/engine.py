@@ -32,6 +32,8 @@ _DTYPES = {torch.float64: "f64", torch.float32: "f32"}
 INFINITY_CACHE_BYTES = 256 << 20     # MI355X die-level L3 (MI355X_MICROARCH.md); sizes the chunk-major schedule
 HBM_STREAM_BYTES_PER_S = 6.7e12      # measured ceiling of the per-step kernel
 LAUNCH_BOUNDARY_S = 2.0e-6           # dependent-launch boundary on one stream (measured 1.5-2.6 us)
+PER_STEP_SPLIT_MIN_S = 16.0e-6       # a per-step launch is split over two streams from this much traffic time on
+PER_STEP_BLOCK = 25                  # steps enqueued per part before switching to the next part's stream
 
 
 def _rows(x, K, N, name):
@@ -57,7 +59,8 @@ class EnsembleEngine:
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
                  device=None, store_trajectory=True, output_steps=None, store_concentrations=True,
                  collect_stats=False, hist=None, hist_ring_steps="auto", hist_ring="bins",
-                 concentration_driven=False, chunk_members="auto", R0=None, S0=None, lib_path=None):
+                 concentration_driven=False, chunk_members="auto", per_step_streams="auto", R0=None, S0=None,
+                 lib_path=None):
         """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
         stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
         store_concentrations=False keeps only the T rows (a 100M-member fp32 run then stores 4 B instead
@@ -83,7 +86,12 @@ class EnsembleEngine:
         Infinity Cache are scheduled chunk-major — all requested steps for members [0, c), then
         [c, 2c), ... — so each chunk's rows stay cache-resident between its consecutive launches
         (+12-15 % at 4-8M members, bit-identical results; members never interact).  "auto" picks c
-        from the bytes per member; an int forces it; None / 0 disables it."""
+        from the bytes per member; an int forces it; None / 0 disables it.
+        per_step_streams: mode='per_step' launches each timestep as this many kernels over contiguous member parts, each
+        part's launches on its own HIP stream, so that one part's launch tail and ramp overlap the other part's kernel
+        (members never interact, so nothing orders the parts against each other).  Two parts: -6.5 % per step at 1M fp64
+        members (36.9 -> 34.5 us), -8 % at 0.5M, -2 % at 4M, +10 % at 0.25M (profiles/r03/two_stream_*.txt), bit-identical
+        results.  "auto": 2 when one step moves at least ~16 us of traffic, else 1; an int forces it."""
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.lib = _capi.load(lib_path)    # raises if the HIP library is not built
@@ -171,6 +179,13 @@ class EnsembleEngine:
         if chunk_members == "auto":
             chunk_members = self.auto_chunk(N, SP, G, dtype)
         self.chunk_members = int(chunk_members or 0) // 256 * 256
+        if per_step_streams == "auto":
+            w_ = 8 if dtype == torch.float64 else 4
+            t_step = min(N, self.chunk_members or N) * w_ * (2 * SP + 4 * G + 7) / HBM_STREAM_BYTES_PER_S
+            per_step_streams = 2 if t_step >= PER_STEP_SPLIT_MIN_S else 1
+        self.per_step_streams = max(1, int(per_step_streams))
+        self._ps_side = []                  # side streams of the per-step parts, created on first use
+        self._ps_unjoined = False           # run(..., join=False) left work on the side streams the caller's has not waited for
         self._R0 = None if R0 is None else np.asarray(R0, dtype=np.float64).reshape(SP, N)
         self._S0 = None if S0 is None else np.asarray(S0, dtype=np.float64).reshape(2, N)
         self.t_next = 0                     # first step not yet run (bookkeeping for checkpoints)
@@ -200,6 +215,8 @@ class EnsembleEngine:
         """Back to the initial condition (zeros, or the R0/S0 given at construction) — the run accumulators too:
         `T_hist` ACCUMULATES over the runs that fill it (a step histogrammed twice counts twice), so it is zeroed here,
         and the per-step moment records are marked not-yet-written."""
+        if self._ps_unjoined:
+            self.join()
         if self._R0 is None:
             self.R.zero_()
         else:
@@ -252,8 +269,10 @@ class EnsembleEngine:
         return out
 
     def load_state_dict(self, state):
-        """Restore a checkpoint.  One WITHOUT summaries (include_outputs=False) restores the state only: the accumulators
+        """Restore a checkpoint (after `join()` if a run(..., join=False) is still outstanding).  One WITHOUT summaries (include_outputs=False) restores the state only: the accumulators
         of this engine (T_hist, per-step moments) are then cleared, because they describe a run this state is not from."""
+        if self._ps_unjoined:
+            self.join()
         for name in ("R", "S") + (("cumE",) if self.cumE is not None else ()):
             dst = getattr(self, name)
             src = np.asarray(state[name], dtype=np.float64)
@@ -336,7 +355,7 @@ class EnsembleEngine:
         _capi.check(self.lib, rc)
         self.t_next = int(t) + 1
 
-    def run(self, t_begin=0, t_end=None, mode="per_step", stream=None, k_steps=None):
+    def run(self, t_begin=0, t_end=None, mode="per_step", stream=None, k_steps=None, join=True):
         """Advance steps [t_begin, t_end).  mode:
         'per_step' one launch per timestep, enqueued from C (the north-star form);
         'graph'    the same launches replayed from a captured hipGraph;
@@ -347,8 +366,14 @@ class EnsembleEngine:
         'tiled'    the time-tiled persistent kernel, `k_steps` steps per launch (None/0: the largest tile
                    that fits the LDS); accumulates `T_hist` inside the time loop if the engine has `hist=`;
         'auto'     'per_step' while a step's HBM traffic hides the launch boundary, else 'ksteps'.
-        Every mode gives bit-identical results."""
+        Every mode gives bit-identical results.
+        join=False (mode 'per_step' on several streams only): do not make the caller's stream wait for the side streams at
+        the end, and do not make the side streams wait for the caller's stream at the start of the NEXT such call — for
+        back-to-back calls with nothing in between that touches the state on the caller's stream (bench.py's repeated
+        blocks): a join is two cross-stream hops, ~20 us.  Call `join()` before anything consumes the results."""
         t_end = self.n_steps if t_end is None else int(t_end)
+        if self._ps_unjoined and mode != "per_step":
+            self.join(stream)
         if mode == "auto":
             k_steps = self.auto_k_steps() if k_steps is None else int(k_steps)
             if k_steps <= 1:
@@ -369,10 +394,7 @@ class EnsembleEngine:
             elif mode == "per_step" and self.T_hist is not None:
                 rc = self._run_per_step_hist(t_begin, t_end, stream)
             elif mode == "per_step":
-                fn = getattr(self.lib, f"fiveeq_run_{self._sfx}")
-                rc = _capi.OK
-                for m0, n in self._chunks():                      # chunk-major: see chunk_members
-                    rc = rc or fn(*self._run_args(t_begin, t_end, m0, n), self._stream(stream))
+                rc = self._run_per_step(t_begin, t_end, stream, join)
             elif mode == "fused" and self.T_hist is not None and self.hist_ring == "bins":
                 rc = self._run_fused_bin_ring(t_begin, t_end, stream)
             elif mode == "fused" and self.T_hist is not None:
@@ -397,6 +419,59 @@ class EnsembleEngine:
                 raise ValueError(f"unknown mode {mode!r}")
         _capi.check(self.lib, rc)
         self.t_next = t_end
+
+    def per_step_launches(self):
+        """[(first member, members, stream index)] of the kernels mode='per_step' launches for ONE timestep, in launch order:
+        member chunks run one after the other (chunk-major, see chunk_members), the parts of a chunk side by side on
+        per_step_streams streams (stream 0 = the caller's)."""
+        out = []
+        for m0, n in self._chunks():
+            k = self.per_step_streams if n >= 512 * self.per_step_streams else 1
+            cuts = [m0 + (i * n // k) // 256 * 256 for i in range(k)] + [m0 + n]
+            out += [(cuts[i], cuts[i + 1] - cuts[i], i) for i in range(k)]
+        return out
+
+    def per_step_stream_list(self, stream=None):
+        """The HIP streams mode='per_step' launches on: the caller's, then the side streams of the other parts."""
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
+        n_streams = 1 + max(i for _, _, i in self.per_step_launches())
+        while len(self._ps_side) < n_streams - 1:
+            self._ps_side.append(torch.cuda.Stream(device=self.device))
+        return [main] + self._ps_side[:n_streams - 1]
+
+    def join(self, stream=None):
+        """Make the caller's stream wait for everything run(..., join=False) enqueued on the side streams."""
+        streams = self.per_step_stream_list(stream)
+        for s in streams[1:]:
+            streams[0].wait_stream(s)
+        self._ps_unjoined = False
+
+    def _run_per_step(self, t_begin, t_end, stream, join=True):
+        fn = getattr(self.lib, f"fiveeq_run_{self._sfx}")
+        launches = self.per_step_launches()
+        streams = self.per_step_stream_list(stream)
+        main = streams[0]
+        if len(streams) == 1:
+            rc = _capi.OK
+            for m0, n, _ in launches:                             # chunk-major: see chunk_members
+                rc = rc or fn(*self._run_args(t_begin, t_end, m0, n), self._stream(main))
+            return rc
+        if not self._ps_unjoined:
+            for s in streams[1:]:
+                s.wait_stream(main)                               # the state may have been touched on the caller's stream
+        rc = _capi.OK
+        chunk_first = [i for i, (_, _, si) in enumerate(launches) if si == 0]
+        for ci, first in enumerate(chunk_first):                  # chunks one after the other, their parts side by side
+            group = launches[first:chunk_first[ci + 1] if ci + 1 < len(chunk_first) else len(launches)]
+            for t in range(int(t_begin), int(t_end), PER_STEP_BLOCK):     # short blocks keep every stream's queue fed
+                t1 = min(int(t_end), t + PER_STEP_BLOCK)
+                for m0, n, si in group:
+                    rc = rc or fn(*self._run_args(t, t1, m0, n), self._stream(streams[si]))
+        if join:
+            for s in streams[1:]:
+                main.wait_stream(s)
+        self._ps_unjoined = not join
+        return rc
 
     def _hist_ring(self, slots=2):
         """Ring [slots, S, N] of T rows + the drive table whose output row is t mod S (shared by the streamed pipelines:

@@ -1280,3 +1280,48 @@ def test_bin_index_ring_equals_the_T_ring_and_keeps_stored_concentrations(gpu):
         assert torch.equal(a.stats_sums(), ref.stats_sums()) and not a._step_sums_valid.any()
         for e in (a, b, ref):
             e.close()
+
+
+def test_per_step_parts_on_two_streams_are_bit_identical(gpu):
+    """mode='per_step' may launch a timestep as several kernels over contiguous member parts on their own streams (one part's
+    launch tail overlaps the other's kernel).  Members never interact: results, statistics records and stored rows must
+    equal the single-launch form bit for bit, for both precisions, with chunk-major on top, resumed mid-run, and on the
+    caller's non-default stream; the automatic choice splits only launches long enough to gain from it."""
+    N, n_steps = 40_000 + 257, 60
+    E = emi.rcp_like_emissions(750, 3)[250:250 + n_steps]
+    for td in (torch.float64, torch.float32):
+        p = prm.sample_ensemble(prm.default_params("multigas"), N, seed=9)
+        ref = _engine(p, N, E, dtype=td, collect_stats=True, per_step_streams=1, chunk_members=0)
+        ref.run(mode="per_step")
+        for streams, chunk in ((2, 0), (3, 0), (2, 16384)):
+            eng = _engine(p, N, E, dtype=td, collect_stats=True, per_step_streams=streams, chunk_members=chunk)
+            lay = eng.per_step_launches()
+            assert sum(n for _, n, _ in lay) == N and max(si for _, _, si in lay) == streams - 1
+            assert all(m0 % 256 == 0 for m0, _, _ in lay) and [m0 for m0, _, _ in lay] == sorted(m0 for m0, _, _ in lay)
+            user = torch.cuda.Stream()
+            with torch.cuda.stream(user):
+                eng.run(0, 23, mode="per_step", stream=user)
+                eng.run(23, n_steps, mode="per_step", stream=user)
+            user.synchronize()
+            for name in ("C", "T", "R", "S", "T_stats"):
+                assert torch.equal(getattr(eng, name), getattr(ref, name)), (td, streams, chunk, name)
+            # back-to-back calls without joins in between (bench.py's repeated blocks), joined once at the end
+            eng.reset_state()
+            for t in range(0, n_steps, 7):
+                eng.run(t, min(n_steps, t + 7), mode="per_step", join=False)
+            assert eng._ps_unjoined
+            eng.join()
+            torch.cuda.current_stream().synchronize()
+            for name in ("C", "T", "R", "S", "T_stats"):
+                assert torch.equal(getattr(eng, name), getattr(ref, name)), (td, streams, chunk, name, "unjoined")
+            eng.run(0, 5, mode="per_step", join=False)
+            eng.reset_state()                                    # joins by itself before it touches the state
+            assert not eng._ps_unjoined and int(eng.R.abs().sum()) == 0
+            eng.close()
+        ref.close()
+    small = _engine(prm.sample_ensemble(prm.default_params("multigas"), 4096), 4096, E)
+    assert small.per_step_streams == 1 and small.per_step_launches() == [(0, 4096, 0)]
+    from fiveeqscm_amd import engine as eng_mod
+    t_1m = 1_000_000 * 248 / eng_mod.HBM_STREAM_BYTES_PER_S
+    assert t_1m >= eng_mod.PER_STEP_SPLIT_MIN_S > 250_000 * 248 / eng_mod.HBM_STREAM_BYTES_PER_S
+    small.close()
