@@ -50,8 +50,9 @@ def main():
             doc = json.load(fh)
     kernels = {k for k, _ in acc}
     for k in sorted(kernels):
-        m = re.match(r"fiveeq::(step|fused|tile)_kernel<(double|float2|float), (\d), (\d), (\d)(?:, (true|false))?>", k)
-        if not m or m.group(6) == "true":
+        # fused_kernel<V, P0, P1, P2, INV, BINS>: the plain forward form only
+        m = re.match(r"fiveeq::(step|fused|tile)_kernel<(double|float2|float), (\d), (\d), (\d)((?:, (?:true|false))*)>", k)
+        if not m or "true" in m.group(6):
             continue
         mean = lambda c: (sum(acc[(k, c)]) / len(acc[(k, c)])) if (k, c) in acc else None   # noqa: E731
         valu, waves = mean("SQ_INSTS_VALU"), mean("SQ_WAVES")
