@@ -503,25 +503,37 @@ class EnsembleEngine:
         lo_h, hi_h, nb = self.hist_spec
         stored = {int(t): r for r, t in enumerate(self.out_steps)}
         w = 8 if self.dtype == torch.float64 else 4
-        st = self._stream(stream)
-        cur = stream if stream is not None else torch.cuda.current_stream(self.device)
         at = lambda t, off: ctypes.c_void_p(0 if t is None else t.data_ptr() + off)   # noqa: E731
-        for m0, n in self._chunks():
+        # the same launch layout as the plain per-step path: chunks one after the other, the parts of a chunk side by
+        # side on their own streams; every part runs its S steps and then histograms its own strip of the ring
+        launches = self.per_step_launches()
+        streams = self.per_step_stream_list(stream)
+        if self._ps_unjoined:
+            self.join(stream)
+        for s_ in streams[1:]:
+            s_.wait_stream(streams[0])
+        chunk_first = [i for i, (_, _, si) in enumerate(launches) if si == 0]
+        rc = _capi.OK
+        for ci, first in enumerate(chunk_first):
+            group = launches[first:chunk_first[ci + 1] if ci + 1 < len(chunk_first) else len(launches)]
             t = int(t_begin)
-            while t < t_end:
+            while t < t_end and rc == _capi.OK:
                 t1 = min(int(t_end), (t // S + 1) * S)
-                rc = run(ctypes.byref(self.model), n, N, self._ptr(ring["drive"]), self.n_steps, t, t1, at(self.r, m0 * w),
-                         at(self.q, m0 * w), at(self.R, m0 * w), at(self.S, m0 * w), ctypes.c_void_p(0), at(buf, m0 * w), S,
-                         at(self.T_stats, (m0 // 64) * self.n_steps * 4 * 8), st)
-                rc = rc or hist(t1 - t, n, N, at(buf[t % S], m0 * w), lo_h, hi_h, nb, self._ptr(self.T_hist[t:t1]), st)
-                if rc != _capi.OK:
-                    return rc
-                with torch.cuda.stream(cur):
-                    for tt in range(t, t1):
-                        if tt in stored:
-                            self.T[stored[tt], m0:m0 + n].copy_(buf[tt % S, m0:m0 + n])
+                for m0, n, si in group:
+                    st = self._stream(streams[si])
+                    rc = rc or run(ctypes.byref(self.model), n, N, self._ptr(ring["drive"]), self.n_steps, t, t1,
+                                   at(self.r, m0 * w), at(self.q, m0 * w), at(self.R, m0 * w), at(self.S, m0 * w),
+                                   ctypes.c_void_p(0), at(buf, m0 * w), S,
+                                   at(self.T_stats, (m0 // 64) * self.n_steps * 4 * 8), st)
+                    rc = rc or hist(t1 - t, n, N, at(buf[t % S], m0 * w), lo_h, hi_h, nb, self._ptr(self.T_hist[t:t1]), st)
+                    with torch.cuda.stream(streams[si]):
+                        for tt in range(t, t1):
+                            if tt in stored:
+                                self.T[stored[tt], m0:m0 + n].copy_(buf[tt % S, m0:m0 + n])
                 t = t1
-        return _capi.OK
+        for s_ in streams[1:]:
+            streams[0].wait_stream(s_)
+        return rc
 
     def _bin_ring(self):
         """Two-slot ring [2, S, N] of uint16 bin indices for the streamed histograms (hist_ring='bins')."""
