@@ -30,3 +30,19 @@ def test_collect_script_references_existing_tools():
             assert re.search(r" -- python3 \$R/", line), line
             if "--pmc" in line:
                 assert "--sys-trace" not in line and "--hip-trace" not in line and "--hsa-trace" not in line and "--stats" not in line
+
+
+def test_bench_numpy_worker_runs_without_torch_or_gpu():
+    """bench.py --numpy-worker: one process of the cpu_baseline's `numpy_nproc` leg.  It must start without importing torch
+    (16 of them run beside the GPU process) and print its compute seconds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--numpy-worker', 'multigas', '3', '4000', '30', '1000', '3000']\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit:\n    pass\n"
+            "assert 'torch' not in sys.modules, 'the worker imported torch'\n" % os.path.join(root, "bench.py"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("numpy-worker")]
+    assert len(line) == 1 and float(line[0].split()[1]) > 0.0
