@@ -223,20 +223,31 @@ def cpu_baseline(kind, G, n_sample, n_steps, numpy_legs=False):
     }
 
 
-def event_timed(eng, launch, t_idx, n_scen, span, batches):
-    """Average duration of one `launch(t, t + span)` (HIP events on the launch stream, queue kept busy ahead of the
-    first event): list of per-launch-unit seconds, one per batch."""
+def event_timed(eng, launch, t_idx, n_scen, span, batches, lanes=None):
+    """Average duration of one `launch(t, t + span)` (HIP events on the launch stream(s), queue kept busy ahead of the
+    first event): list of seconds per batch.  `lanes`: the streams the launches run on when a timestep is several
+    concurrent launches (engine.per_step_stream_list()); `launch` must then not join them (run(..., join=False)): an event
+    is recorded on every lane and a batch lasts as long as its slowest lane takes from mark to mark."""
     samples = []
     lead = min(5, max(1, span))
+    lanes = lanes or [torch.cuda.current_stream()]
+
+    def mark():
+        evs = [torch.cuda.Event(enable_timing=True) for _ in lanes]
+        for ev, lane in zip(evs, lanes):
+            ev.record(lane)
+        return evs
+
     for i in range(max(batches, 1)):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t = (t_idx + i * span) % max(1, n_scen - span - lead)          # t + lead + span <= n_scen always
-        launch(t, t + lead)                                             # keep the queue busy ahead of the first event
-        e0.record()
+        launch(t, t + lead)                                             # keep the queues busy ahead of the first events
+        m0 = mark()
         launch(t + lead, t + lead + span)
-        e1.record()
-        e1.synchronize()
-        samples.append(e0.elapsed_time(e1) * 1e-3)
+        m1 = mark()
+        eng.join()
+        for ev in m1:
+            ev.synchronize()
+        samples.append(max(a_.elapsed_time(b_) for a_, b_ in zip(m0, m1)) * 1e-3)
     return np.array(samples)
 
 
@@ -476,8 +487,9 @@ def main():
         n_launch = len(layout)
         members_per_launch = n_local / n_launch
         per_batch = 100
-        samples = event_timed(eng, lambda t0_, t1_: eng.run(t0_, t1_, mode=a.mode if a.mode == "graph" else "per_step"),
-                              t_idx, n_scen, per_batch, a.kernel_batches)
+        ev_mode = a.mode if a.mode == "graph" else "per_step"
+        samples = event_timed(eng, lambda t0_, t1_: eng.run(t0_, t1_, mode=ev_mode, join=False), t_idx, n_scen, per_batch,
+                              a.kernel_batches, lanes=eng.per_step_stream_list() if ev_mode == "per_step" else None)
         samples = samples / (per_batch * n_seq)
         k_avg = float(samples.mean())
         achieved = A * members_per_launch * conc / k_avg / 1e9
@@ -617,7 +629,8 @@ def main():
         w = 8 if a.dtype == "f64" else 4
         resident = w * (eng.sum_pools + 2 + 3 * G + 2) * n_big
         big.run(0, 6)
-        sm = event_timed(big, lambda t0_, t1_: big.run(t0_, t1_), 0, n_s, 100, 1) / 100
+        sm = event_timed(big, lambda t0_, t1_: big.run(t0_, t1_, join=False), 0, n_s, 100, 1,
+                         lanes=big.per_step_stream_list()) / 100
         Ab = big.bytes_per_member_step("per_step")
         ach = Ab * n_big / float(sm.mean()) / 1e9
         roofline["hbm_resident"] = {"members": n_big, "state_and_parameter_bytes": resident,
