@@ -1,3 +1,9 @@
+#!/usr/bin/env bash
+# Run ON THE GPU BOX (via gpurun) from the repo root, AFTER `tools/collect_profiles.sh r03 quick` has produced the
+# counter files and they were copied to profiles/: re-collects the fp32 SQ passes (instructions, packed share), merges
+# them into profiles/valu.json, then regenerates EVERY bench line and the kernel trace under gpurun_out/r03k/, so that no
+# committed bench line was produced with an older valu.json / traffic.json than the one committed beside it.
+# rocprofv3 is always given `python3 script` directly after `--`; --pmc passes carry --kernel-trace only.
 set -u
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03k; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 cp $R/profiles/valu.json $OUT/valu.json
