@@ -476,20 +476,21 @@ def main():
     if not fusedlike:
         A = eng.bytes_per_member_step("per_step")
         # One timestep = n_seq member chunks one after the other (chunk-major schedule of large ensembles) x `conc` parts of
-        # a chunk side by side on their own HIP streams (engine.per_step_streams; graph replay keeps one stream).  The
+        # a chunk side by side on their own HIP streams (engine.per_step_streams; graph replay uses the same layout).  The
         # launches of the `conc` parts overlap fully — each stream issues its next kernel the moment its last one ends — so
         # the period of a chunk's step is also what each of those kernels lasts: `avg_launch_us` below is that period, the
         # figure rocprofv3 --kernel-trace reports as the kernel's average duration, and the chip moves `conc` launches'
         # bytes in it.
-        layout = eng.per_step_launches() if a.mode == "per_step" else [(m0_, n_, 0) for m0_, n_ in eng._chunks()]
+        layout = eng.per_step_launches()
         conc = 1 + max(si for _, _, si in layout)
         n_seq = len(layout) // conc
         n_launch = len(layout)
         members_per_launch = n_local / n_launch
         per_batch = 100
-        ev_mode = a.mode if a.mode == "graph" else "per_step"
-        samples = event_timed(eng, lambda t0_, t1_: eng.run(t0_, t1_, mode=ev_mode, join=False), t_idx, n_scen, per_batch,
-                              a.kernel_batches, lanes=eng.per_step_stream_list() if ev_mode == "per_step" else None)
+        # (--mode graph replays the same kernels in the same layout: their duration is measured on eagerly enqueued launches,
+        # so that no graph capture falls between two marks)
+        samples = event_timed(eng, lambda t0_, t1_: eng.run(t0_, t1_, mode="per_step", join=False), t_idx, n_scen, per_batch,
+                              a.kernel_batches, lanes=eng.per_step_stream_list())
         samples = samples / (per_batch * n_seq)
         k_avg = float(samples.mean())
         achieved = A * members_per_launch * conc / k_avg / 1e9

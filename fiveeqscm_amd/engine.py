@@ -412,9 +412,18 @@ class EnsembleEngine:
                 rc = fn(*self._run_args(t_begin, t_end), int(k_steps or 0), lo_h, hi_h, nb, self._ptr(self.T_hist),
                         self._stream(stream))
             elif mode == "graph":
+                # one captured plan per (chunk, part), the parts of a chunk replayed side by side on their own streams
                 rc = _capi.OK
-                for plan in self.prepare_graph(t_begin, t_end):
-                    rc = rc or self.lib.fiveeq_plan_launch(plan, self._stream(stream))
+                plans = self.prepare_graph(t_begin, t_end)
+                streams = self.per_step_stream_list(stream)
+                if self._ps_unjoined:
+                    self.join(stream)
+                for s_ in streams[1:]:
+                    s_.wait_stream(streams[0])
+                for plan, (_, _, si) in zip(plans, self.per_step_launches()):
+                    rc = rc or self.lib.fiveeq_plan_launch(plan, self._stream(streams[si]))
+                for s_ in streams[1:]:
+                    streams[0].wait_stream(s_)
             else:
                 raise ValueError(f"unknown mode {mode!r}")
         _capi.check(self.lib, rc)
@@ -653,8 +662,8 @@ class EnsembleEngine:
         return int(getattr(self.lib, f"fiveeq_tile_steps_{self._sfx}")(nb))
 
     def prepare_graph(self, t_begin=0, t_end=None):
-        """Capture (once) the per-step launches of [t_begin, t_end) into hipGraph plans, one per
-        member chunk; returns the list of plans in launch order."""
+        """Capture (once) the per-step launches of [t_begin, t_end) into hipGraph plans, one per launch of
+        `per_step_launches()` (member chunk x part); returns the list of plans in that order."""
         t_end = self.n_steps if t_end is None else int(t_end)
         key = (int(t_begin), t_end)
         plans = self._plans.get(key)
@@ -663,7 +672,7 @@ class EnsembleEngine:
             self._wave_stats()
             fn = getattr(self.lib, f"fiveeq_plan_create_{self._sfx}")
             with torch.cuda.device(self.device):
-                for m0, n in self._chunks():
+                for m0, n, _ in self.per_step_launches():
                     plan = ctypes.c_void_p()
                     _capi.check(self.lib, fn(*self._run_args(t_begin, t_end, m0, n), ctypes.byref(plan)))
                     plans.append(plan)

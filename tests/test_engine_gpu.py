@@ -1314,6 +1314,13 @@ def test_per_step_parts_on_two_streams_are_bit_identical(gpu):
             torch.cuda.current_stream().synchronize()
             for name in ("C", "T", "R", "S", "T_stats"):
                 assert torch.equal(getattr(eng, name), getattr(ref, name)), (td, streams, chunk, name, "unjoined")
+            # graph replay: one captured plan per part, replayed side by side on the same streams
+            eng.reset_state()
+            eng.run(mode="graph")
+            torch.cuda.synchronize()
+            assert len(eng.prepare_graph()) == len(lay)
+            for name in ("C", "T", "R", "S", "T_stats"):
+                assert torch.equal(getattr(eng, name), getattr(ref, name)), (td, streams, chunk, name, "graph")
             eng.run(0, 5, mode="per_step", join=False)
             eng.reset_state()                                    # joins by itself before it touches the state
             assert not eng._ps_unjoined and int(eng.R.abs().sum()) == 0
