@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FIVEEQ_LIB_PATH selects another build of the same library (e.g. the host-sanitizer build of tools/sanitize_host.sh)
 LIB_PATH = os.environ.get("FIVEEQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_GAS = 3
 MAX_POOLS = 4
 N_BOX = 2
@@ -83,6 +83,8 @@ SIGNATURES = {
     "fiveeq_run_fused_bins_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.c_double, ctypes.c_double, _i32, _p, _i32, _p]),
     "fiveeq_run_fused_bins_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.c_double, ctypes.c_double, _i32, _p, _i32, _p]),
     "fiveeq_hist_bins": (ctypes.c_int, [_i32, _i64, _i64, _p, _i32, _p, _p]),
+    "fiveeq_run_bins_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.c_double, ctypes.c_double, _i32, _p, _i32, _p]),
+    "fiveeq_run_bins_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.c_double, ctypes.c_double, _i32, _p, _i32, _p]),
     "fiveeq_plan_create_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.POINTER(_p)]),
     "fiveeq_plan_create_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [ctypes.POINTER(_p)]),
     "fiveeq_run_inverse_f64": (ctypes.c_int, _RUN_ARGS[:11] + [_p] + _RUN_ARGS[11:]),

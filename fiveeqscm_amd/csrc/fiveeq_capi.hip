@@ -150,6 +150,14 @@ struct RunArgs {
     double* stats;
 };
 
+// the bin-index ring of the streamed histograms (fused_kernel<..., BINS = true>)
+struct BinRing {
+    unsigned short* ring = nullptr;
+    int ring_rows = 0;
+    double lo = 0.0, inv_w = 0.0;
+    int n_bins = 0;
+};
+
 // ---- packed fp32 lanes: two members per lane (fiveeq_device.hpp, "Lane value types") ----------------------------
 // The fp32 entry points run the packed kernels whenever the rows allow 8-byte accesses: even row stride, every row
 // pointer 8-byte aligned, at least two members.  Otherwise (odd ld, a sub-range starting at an odd member) the
@@ -173,10 +181,10 @@ struct LaneOf<float> {
     }
 };
 
-template <typename T>
-int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
+template <typename T, bool BINS = false>
+int launch_step(const RunArgs<T>& a, int t, hipStream_t st, const BinRing& br = BinRing()) {
     using P = typename LaneOf<T>::Packed;
-    const bool packed = LaneOf<T>::can_pack(a);
+    const bool packed = LaneOf<T>::can_pack(a) && (!BINS || (((uintptr_t)br.ring) & 3) == 0);
     const int64_t per_block = (int64_t)FIVEEQ_STEP_BLOCK * (packed ? 2 : 1);
     const int64_t blocks = (a.n + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
@@ -185,11 +193,13 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
 #define X(p0, p1, p2)                                                                             \
     case (p0) * 100 + (p1) * 10 + (p2):                                                           \
         if (packed)                                                                               \
-            hipLaunchKernelGGL((step_kernel<P, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
-                               a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);            \
+            hipLaunchKernelGGL((step_kernel<P, p0, p1, p2, BINS>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
+                               a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, br.ring, br.ring_rows,     \
+                               br.lo, br.inv_w, br.n_bins);                                       \
         else                                                                                      \
-            hipLaunchKernelGGL((step_kernel<T, p0, p1, p2>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
-                               a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);            \
+            hipLaunchKernelGGL((step_kernel<T, p0, p1, p2, BINS>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
+                               a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, br.ring, br.ring_rows,     \
+                               br.lo, br.inv_w, br.n_bins);                                       \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X
@@ -199,14 +209,6 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st) {
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;
 }
-
-// the bin-index ring of the streamed histograms (fused_kernel<..., BINS = true>)
-struct BinRing {
-    unsigned short* ring = nullptr;
-    int ring_rows = 0;
-    double lo = 0.0, inv_w = 0.0;
-    int n_bins = 0;
-};
 
 template <typename T, bool INV, bool BINS = false>
 int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream_t st, const BinRing& br = BinRing()) {
@@ -283,10 +285,10 @@ int run_fused(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     return launch_fused<T, false>(a, t_begin, t_end, nullptr, (hipStream_t)stream);
 }
 
-template <typename T>
-int run_fused_bins(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
-                   int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats,
-                   double lo, double hi, int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
+template <typename T, bool FUSED>
+int run_bins(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
+             int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats,
+             double lo, double hi, int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
     RunArgs<T> a;
     if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
     if (n_bins < 1 || n_bins > HIST_MAX_BINS) return fail(FIVEEQ_E_INVALID, "n_bins=%d outside 1..%d", n_bins, HIST_MAX_BINS);
@@ -301,7 +303,10 @@ int run_fused_bins(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive,
     br.lo = lo;
     br.inv_w = (double)n_bins / (hi - lo);
     br.n_bins = n_bins;
-    return launch_fused<T, false, true>(a, t_begin, t_end, nullptr, (hipStream_t)stream, br);
+    if (FUSED) return launch_fused<T, false, true>(a, t_begin, t_end, nullptr, (hipStream_t)stream, br);
+    for (int t = t_begin; t < t_end; ++t)                 // the per-step form: one launch per timestep
+        if (int rc = launch_step<T, true>(a, t, (hipStream_t)stream, br)) return rc;
+    return FIVEEQ_OK;
 }
 
 template <typename T>
@@ -584,15 +589,29 @@ int fiveeq_run_fused_bins_f64(const fiveeq_model* model, int64_t n_members, int6
                               int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
                               double* S, double* C_traj, double* T_traj, int32_t n_rows, double* T_stats, double hist_lo,
                               double hist_hi, int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
-    return run_fused_bins<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+    return run_bins<double, true>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
                                   T_stats, hist_lo, hist_hi, n_bins, bin_ring, ring_rows, stream);
 }
 int fiveeq_run_fused_bins_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
                               int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
                               float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, double hist_lo,
                               double hist_hi, int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
-    return run_fused_bins<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+    return run_bins<float, true>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
                                  T_stats, hist_lo, hist_hi, n_bins, bin_ring, ring_rows, stream);
+}
+int fiveeq_run_bins_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive, int32_t n_steps,
+                        int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R, double* S,
+                        double* C_traj, double* T_traj, int32_t n_rows, double* T_stats, double hist_lo, double hist_hi,
+                        int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
+    return run_bins<double, false>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                                   T_stats, hist_lo, hist_hi, n_bins, bin_ring, ring_rows, stream);
+}
+int fiveeq_run_bins_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive, int32_t n_steps,
+                        int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R, float* S,
+                        float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, double hist_lo, double hist_hi,
+                        int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
+    return run_bins<float, false>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                                  T_stats, hist_lo, hist_hi, n_bins, bin_ring, ring_rows, stream);
 }
 int fiveeq_plan_create_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
                            int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,

@@ -728,12 +728,23 @@ __device__ __forceinline__ void wave_stats_flush(const float2v* tile /* [STAT_ST
 // 256-thread workgroups with identical buffers, profiles/r01/ab_variants.txt) and owns the same
 // members in every launch.
 // ---------------------------------------------------------------------------------
+// BINS = true: the streamed-histogram form.  Besides everything above, the kernel writes the histogram BIN INDEX of T of every
+// step (fiveeq_hist_rows' bin rule, bit for bit; 0xFFFF for a NaN) as one uint16 per member into a ring
+// bin_ring[ring_rows][ld] at row t mod ring_rows — 2 bytes per member-step where a ring of T rows takes w — for the
+// histogram pass (hist_bins_kernel) to count.  The pass no longer sees T, so the moments stay in the kernel (stats).
+constexpr unsigned short BIN_NAN = 0xFFFFu;
+__device__ __forceinline__ unsigned int fe_hist_bin(const double v, const double lo, const double inv_w, const int n_bins) {
+    const double pos = (v - lo) * inv_w;
+    const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
+    return v == v ? (unsigned int)b : (unsigned int)BIN_NAN;
+}
+
 #ifdef FIVEEQ_STEP_WAVES
 #define FIVEEQ_STEP_ATTR __attribute__((amdgpu_waves_per_eu(FIVEEQ_STEP_WAVES, FIVEEQ_STEP_WAVES)))
 #else
 #define FIVEEQ_STEP_ATTR
 #endif
-template <typename V, int P0, int P1, int P2>
+template <typename V, int P0, int P1, int P2, bool BINS = false>
 __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kernel(
     const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps, const int t,
     const int64_t n, const int64_t ld,
@@ -741,7 +752,9 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
     typename Lane<V>::S* __restrict__ R, typename Lane<V>::S* __restrict__ S,
     typename Lane<V>::S* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */,
     typename Lane<V>::S* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
-    const int n_rows, double* __restrict__ stats /* [ceil(n/64)][n_steps][4] or nullptr */) {
+    const int n_rows, double* __restrict__ stats /* [ceil(n/64)][n_steps][4] or nullptr */,
+    unsigned short* __restrict__ bin_ring /* BINS: [ring_rows][ld], row t mod ring_rows */, const int ring_rows,
+    const double hist_lo, const double hist_inv_w, const int n_bins) {
     using L = Layout<P0, P1, P2>;
     using T = typename Lane<V>::S;
     constexpr int W = Lane<V>::W;                 // members per lane
@@ -795,6 +808,17 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
             }
             if (T_traj != nullptr) store_lane(T_traj + (int64_t)row * ld + m, Tn, full);
         }
+        if constexpr (BINS) {                                            // the histogram bin of T, 2 bytes per member
+            unsigned short* o = bin_ring + (int64_t)(t % ring_rows) * ld + m;
+            if constexpr (W == 1) {
+                *o = (unsigned short)fe_hist_bin((double)Tn, hist_lo, hist_inv_w, n_bins);
+            } else {
+                const unsigned int b0 = fe_hist_bin((double)Tn.x, hist_lo, hist_inv_w, n_bins);
+                const unsigned int b1 = fe_hist_bin((double)Tn.y, hist_lo, hist_inv_w, n_bins);
+                if (full) *reinterpret_cast<unsigned int*>(o) = b0 | (b1 << 16);
+                else *o = (unsigned short)b0;
+            }
+        }
         }
     }
     if (stats != nullptr) {
@@ -821,17 +845,6 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
 // INV = true: concentration-driven form.  drive[t][0..2] are target concentrations, cumE [G][ld] is
 // per-member cumulative-emission state (in/out), and C_traj receives the DIAGNOSED EMISSIONS.
 // (112 VGPRs at fp64 4+1+1 = 4 waves/SIMD; launch-bounds hints for 5 or 6 waves spill: -3 % / -16 %.)
-// BINS = true: the streamed-histogram form.  Besides everything above, the kernel writes the histogram BIN INDEX of T of every
-// step (fiveeq_hist_rows' bin rule, bit for bit; 0xFFFF for a NaN) as one uint16 per member into a ring
-// bin_ring[ring_rows][ld] at row t mod ring_rows — 2 bytes per member-step where a ring of T rows takes w — for the
-// histogram pass (hist_bins_kernel) to count.  The pass no longer sees T, so the moments stay in the kernel (stats).
-constexpr unsigned short BIN_NAN = 0xFFFFu;
-__device__ __forceinline__ unsigned int fe_hist_bin(const double v, const double lo, const double inv_w, const int n_bins) {
-    const double pos = (v - lo) * inv_w;
-    const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
-    return v == v ? (unsigned int)b : (unsigned int)BIN_NAN;
-}
-
 template <typename V, int P0, int P1, int P2, bool INV, bool BINS = false>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps,

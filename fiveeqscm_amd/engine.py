@@ -77,7 +77,8 @@ class EnsembleEngine:
                                statistics; T rows only, no stored concentrations).  "auto" ring length: what 8 GB of T
                                ring would hold, at most 128 steps;
           run(mode="tiled")    accumulates it INSIDE the kernel's time loop (LDS-privatised, no scratch memory);
-          run(mode="per_step") histograms each step's T row right behind the step kernel (one scratch row).
+          run(mode="per_step") the per-step kernel writes the bin indices (or, hist_ring="T", T) of S steps into a ring strip and a
+                               histogram launch counts the strip right behind it.
         concentration_driven: inverse mode — `emissions` holds the TARGET concentrations [n_steps, G]
         at the end of each step (shared by all members); the per-member emissions that reach them
         are diagnosed into `self.E` ([n_rows, G, N], aliasing `self.C`), and `self.cumE` [G, N] is
@@ -500,9 +501,11 @@ class EnsembleEngine:
         the plain per-step path) stores T of S = hist_ring_steps consecutive steps into a ring strip, then ONE histogram
         launch over those S rows adds them into T_hist[t:t+S].  Two C calls per S steps and member chunk; the in-kernel
         per-wave moments stay on (they are free in this kernel)."""
+        if self.hist_ring == "bins":
+            return self._run_per_step_bin_ring(t_begin, t_end, stream)
         if self.C is not None:
-            raise RuntimeError("per-step histograms carry T only: build the engine with store_concentrations=False "
-                               "(or store_trajectory=False), or use mode='tiled'")
+            raise RuntimeError("per-step histograms through a T ring carry T only: build the engine with "
+                               "store_concentrations=False (or store_trajectory=False), or use hist_ring='bins'")
         N = self.n_members
         ring = self._hist_ring(slots=1)
         S = ring["S"]
@@ -539,6 +542,42 @@ class EnsembleEngine:
                         for tt in range(t, t1):
                             if tt in stored:
                                 self.T[stored[tt], m0:m0 + n].copy_(buf[tt % S, m0:m0 + n])
+                t = t1
+        for s_ in streams[1:]:
+            streams[0].wait_stream(s_)
+        return rc
+
+    def _run_per_step_bin_ring(self, t_begin, t_end, stream):
+        """mode='per_step' with hist= and hist_ring='bins': fiveeq_run_bins_* — the per-step kernel, one launch per timestep
+        and member part, the engine's own drive table, stored C/T rows and wave records as in a plain per-step run — also
+        writes every member's histogram bin into a ring strip [S, N] of uint16 (row t mod S); after S steps each part counts
+        its strip into T_hist (fiveeq_hist_bins) on its own stream.  2 bytes written + 2 read per member-step on top of the
+        step's 124 / 248."""
+        N = self.n_members
+        ring = self._bin_ring()
+        S = ring["S"]
+        buf = ring["buf"][0]
+        run = getattr(self.lib, f"fiveeq_run_bins_{self._sfx}")
+        lo_h, hi_h, nb = self.hist_spec
+        at = lambda t, off: ctypes.c_void_p(0 if t is None else t.data_ptr() + off)   # noqa: E731
+        launches = self.per_step_launches()
+        streams = self.per_step_stream_list(stream)
+        if self._ps_unjoined:
+            self.join(stream)
+        for s_ in streams[1:]:
+            s_.wait_stream(streams[0])
+        chunk_first = [i for i, (_, _, si) in enumerate(launches) if si == 0]
+        rc = _capi.OK
+        for ci, first in enumerate(chunk_first):
+            group = launches[first:chunk_first[ci + 1] if ci + 1 < len(chunk_first) else len(launches)]
+            t = int(t_begin)
+            while t < t_end and rc == _capi.OK:
+                t1 = min(int(t_end), (t // S + 1) * S)
+                for m0, n, si in group:
+                    st = self._stream(streams[si])
+                    rc = rc or run(*self._run_args(t, t1, m0, n), lo_h, hi_h, nb, at(buf, m0 * 2), S, st)
+                    rc = rc or self.lib.fiveeq_hist_bins(t1 - t, n, N, at(buf[t % S], m0 * 2), nb,
+                                                         self._ptr(self.T_hist[t:t1]), st)
                 t = t1
         for s_ in streams[1:]:
             streams[0].wait_stream(s_)
@@ -765,6 +804,8 @@ class EnsembleEngine:
         if mode in ("ksteps", "tiled"):
             k = k_steps or (self.auto_k_steps() if mode == "ksteps" else self.tile_steps())
             return w * (out + (2 * SP + 3 * G + 6) / max(int(k), 1)) + extra
+        if mode == "per_step" and self.T_hist is not None and self.hist_ring == "bins":
+            ring = 4.0
         return w * (2 * SP + 3 * G + 6 + out) + extra + ring
 
 

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   6
+#define FIVEEQ_ABI_VERSION   7
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
@@ -286,6 +286,20 @@ int fiveeq_run_fused_bins_f32(const fiveeq_model *model, int64_t n_members, int6
                               uint16_t *bin_ring, int32_t ring_rows, void *stream);
 int fiveeq_hist_bins(int32_t n_rows, int64_t n_members, int64_t ld, const uint16_t *bins, int32_t n_bins,
                      uint64_t *hist, void *stream);
+/* the same for the PER-STEP form: fiveeq_run_* (one launch per timestep) whose kernel also writes the bin index of T —
+ * 2 bytes per member-step on top of the step's w(2 SP + 4 G + 7), where a ring of T rows adds w written + w re-read */
+int fiveeq_run_bins_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                        const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                        const double *r, const double *q, double *R, double *S,
+                        double *C_traj, double *T_traj, int32_t n_rows, double *T_stats,
+                        double hist_lo, double hist_hi, int32_t n_bins,
+                        uint16_t *bin_ring, int32_t ring_rows, void *stream);
+int fiveeq_run_bins_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                        const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                        const float *r, const float *q, float *R, float *S,
+                        float *C_traj, float *T_traj, int32_t n_rows, double *T_stats,
+                        double hist_lo, double hist_hi, int32_t n_bins,
+                        uint16_t *bin_ring, int32_t ring_rows, void *stream);
 
 /* new — shard-computable Latin hypercube: out[k][i] = u_{dim0+k}(m0 + i),
  * 0 <= i < n_members, 0 <= k < n_dim, for a design over n_total members:

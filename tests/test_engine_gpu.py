@@ -1278,7 +1278,18 @@ def test_bin_index_ring_equals_the_T_ring_and_keeps_stored_concentrations(gpu):
         for name in ("C", "T", "R", "S", "T_stats"):
             assert torch.equal(getattr(a, name), getattr(ref, name)), (N, td, name)
         assert torch.equal(a.stats_sums(), ref.stats_sums()) and not a._step_sums_valid.any()
-        for e in (a, b, ref):
+        # the per-step form of the same ring: the step kernel writes the bin indices; stored C rows allowed here too
+        c = _engine(p, N, E, dtype=td, collect_stats=True, hist=(lo, hi, nb), hist_ring_steps=int(rng.integers(1, 9)),
+                    per_step_streams=int(rng.integers(1, 3)))
+        c.run(0, 17, mode="per_step")
+        c.run(17, n_steps, mode="per_step")
+        torch.cuda.synchronize()
+        assert torch.equal(c.T_hist, a.T_hist), (N, td, nb, "per_step")
+        for name in ("C", "T", "R", "S"):
+            assert torch.equal(getattr(c, name), getattr(ref, name)), (N, td, name, "per_step")
+        sc, sr = c.stats_sums(), ref.stats_sums()
+        assert torch.equal(sc[:, [0, 3, 4]], sr[:, [0, 3, 4]]) and torch.allclose(sc[:, 1:3], sr[:, 1:3], rtol=1e-13, atol=1e-11)
+        for e in (a, b, c, ref):
             e.close()
 
 
