@@ -236,6 +236,10 @@ def test_abi_v6_bin_ring_entry_points_validate_on_the_host():
     assert bins(0.0, 1.0, 16, ctypes.c_void_p(0x1001), 4) == _capi.E_INVALID and b"aligned" in lib.fiveeq_last_error()
     empty = (ctypes.byref(m), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, None)
     assert lib.fiveeq_run_fused_bins_f32(*empty, 0.0, 1.0, 16, p, 4, None) == _capi.OK           # empty span: nothing to do
+    # the per-step form shares the checks
+    assert lib.fiveeq_run_bins_f64(*common, 0.0, 1.0, 16, None, 4, None) == _capi.E_INVALID and b"bin_ring" in lib.fiveeq_last_error()
+    assert lib.fiveeq_run_bins_f32(*common, 2.0, 1.0, 16, p, 4, None) == _capi.E_INVALID
+    assert lib.fiveeq_run_bins_f32(*empty, 0.0, 1.0, 16, p, 4, None) == _capi.OK
     count = lambda rows, n, ld, b, nb, h: lib.fiveeq_hist_bins(rows, n, ld, b, nb, h, None)       # noqa: E731
     assert count(-1, 8, 8, p, 16, p) == _capi.E_INVALID and count(2, 0, 8, p, 16, p) == _capi.E_INVALID
     assert count(2, 9, 8, p, 16, p) == _capi.E_INVALID and count(2, 8, 8, p, 0, p) == _capi.E_INVALID
