@@ -78,7 +78,9 @@ def main():
             rec["packed_per_wave_step"] = share * (nf + nm + na) / waves / steps
             rec["fma_mul_add_trans_per_wave_step"] = [x / waves / steps for x in (nf, nm, na, ntr)]
         gui, durs = mean("GRBM_GUI_ACTIVE"), dur.get(k)
-        if gui and durs:                                             # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles; only meaningful over a long kernel (the time-fused family): a
+        # 20-us per-step launch is dominated by the counter's start / stop window
+        if gui and durs and sum(durs) / len(durs) > 500.0:
             rec["clock_GHz_under_load"] = gui / 8.0 / (sum(durs) / len(durs) * 1e-6) / 1e9
         for c, nm in (("SQ_INSTS_SALU", "salu_per_wave_step"), ("SQ_INSTS_LDS", "lds_per_wave_step"),
                       ("SQ_INSTS_VMEM_RD", "vmem_rd_per_wave_step"), ("SQ_INSTS_VMEM_WR", "vmem_wr_per_wave_step")):
