@@ -370,7 +370,7 @@ template <typename T>
 constexpr int tile_static_lds() {
     constexpr int lane_bytes = 8;                          // double, or float2v
     return (int)(sizeof(T) * TILE_MAX_STEPS * DRIVE_STRIDE + lane_bytes * (TILE_BLOCK / 64) * STAT_STEPS * STAT_ROW +
-                 sizeof(KModel<T>));
+                 sizeof(KModel<T>) + 8 /* the work-item counter, padded to a lane */);
 }
 // largest K whose histogram [K][ceil(n_bins/2)] dwords fits beside the kernel's static LDS
 template <typename T>
@@ -424,18 +424,17 @@ int launch_tile(const RunArgs<T>& a, int t_begin, int t_end, double lo, double i
     const int64_t wgs = (int64_t)cus * (1024 / TILE_BLOCK);
     const dim3 grid((unsigned)(n_blocks < wgs ? n_blocks : wgs)), block(TILE_BLOCK);
     const size_t dyn = hist ? (size_t)(t_end - t_begin) * ((n_bins + 1) / 2) * 4 : 0;
-    static const int stagger = getenv("FIVEEQ_TILE_STAGGER") ? atoi(getenv("FIVEEQ_TILE_STAGGER")) : 0;
     switch (a.code) {
 #define X(p0, p1, p2)                                                                                        \
     case (p0) * 100 + (p1) * 10 + (p2):                                                                      \
         if (packed)                                                                                          \
             hipLaunchKernelGGL((tile_kernel<P, p0, p1, p2>), grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, \
                                a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, \
-                               hist, stagger);                                                               \
+                               hist);                                                               \
         else                                                                                                 \
             hipLaunchKernelGGL((tile_kernel<T, p0, p1, p2>), grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, \
                                a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, \
-                               hist, stagger);                                                               \
+                               hist);                                                               \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X

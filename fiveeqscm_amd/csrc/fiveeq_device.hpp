@@ -878,6 +878,9 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const int n_valid = (int)min((int64_t)64 * W, n - wave * 64 * W);               // members of this wave (<= 0: none)
     int ks = 0;                                                                      // steps parked in the tile
 
+#ifdef FIVEEQ_FUSED_TIMING          // experiment builds (tools/fused_timing.py): when and where does each wave run
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
     if constexpr (INV) {
 #pragma unroll
@@ -942,6 +945,15 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
             }
         }
     }
+#ifdef FIVEEQ_FUSED_TIMING          // the wave's statistics record of the LAST step is overwritten: start, end (100 MHz), HW_ID, XCC_ID
+    if (wave_live && (threadIdx.x & 63) == 0) {
+        double* o = stats + ((int64_t)W * wave * n_steps + (t_end - 1)) * 4;
+        o[0] = (double)dbg_t0;
+        o[1] = (double)wall_clock64();
+        o[2] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        o[3] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     if (active) {
 #pragma unroll
         for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
@@ -963,8 +975,9 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
 // per workgroup does not help while a workgroup sees only 256 members per step — their T values land
 // in ~256 different bins.  What helps is funnelling MANY members through one LDS histogram for the
 // SAME steps.  So: one launch covers a tile of K = t_end - t_begin steps for ALL members; the grid is
-// one persistent 1024-thread workgroup per CU that walks over member blocks of 1024 — load state and
-// parameters, K steps in registers, store state — and keeps hist[K][n_bins] in LDS across all of its
+// one persistent 1024-thread workgroup per CU whose waves work through its member blocks of 1024 lanes
+// (wave items, see below) — load state and parameters, K steps in registers, store state — and keeps
+// hist[K][n_bins] in LDS across all of its
 // blocks (ds_add_u32 on packed 16-bit pairs: 2 bins per dword, so K x 4096 bins = K x 8 KiB).  At the
 // end (or every 63 blocks: 63 x 1024 < 2^16, a 16-bit lane cannot overflow) the non-zero bins go to
 // the global 64-bit counters — consecutive lanes flush consecutive bins, and the occupied bins of a
@@ -979,7 +992,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
 #define FIVEEQ_TILE_BLOCK 1024
 #endif
 constexpr int TILE_BLOCK = FIVEEQ_TILE_BLOCK;
-constexpr int TILE_MAX_STEPS = 32;
+constexpr int TILE_MAX_STEPS = 64;
 // blocks a workgroup may histogram before it flushes: a 16-bit lane of the packed LDS counters must not overflow
 template <typename V>
 constexpr int tile_flush_blocks() { return 65535 / (TILE_BLOCK * Lane<V>::W); }      // 63 x 1024 (31 x 2048) <= 65535
@@ -996,8 +1009,18 @@ __device__ __forceinline__ void tile_hist_add(unsigned int* h_row, const double 
 
 // V = lane value type: one member per lane, or two (packed fp32: a block is 2048 members and the kernel keeps the fused
 // packed kernel's 4 waves/SIMD x 2 members, where the one-member fp32 form is held to 4 waves x 1 by its 1024-thread
-// workgroup — SQ counters, profiles/r03/tile_vs_ksteps_K32_f32_4M.csv: at 4 waves/SIMD its VALU issues 24 % less densely
-// than the 6-wave fused kernel's).
+// workgroup).
+//
+// Work is handed to WAVES, not fixed per wave (round 3, profiles/r03/ab_variants.txt section 14).  A SIMD's instruction
+// arbiter favours its oldest wave: of four waves that start together and run the same 750-step loop, the first finishes
+// after ~60 % of the time the last one needs (tools/fused_timing.py).  A kernel with more workgroups than slots does not
+// care — a new workgroup takes the freed slot — but a persistent workgroup whose waves each own 1/16 of every member block
+// ends with one or two waves per SIMD crawling through their share alone (a lone wave issues at 40 % of the rate of four):
+// that tail, not the load/store phases, was the cost of this kernel's shape (+23 % on the fused kernel relaunched every K
+// steps, same instruction count).  So the workgroup's member blocks are cut into wave items (64 lanes x W members x K
+// steps) behind one LDS counter; a wave takes the next item when it finishes one, and all sixteen finish within one item
+// of each other.  Items are handed out in epochs of as many members as a 16-bit histogram lane can count; the
+// workgroup meets at the end of an epoch to flush.
 template <typename V, int P0, int P1, int P2>
 __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
     const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps,
@@ -1006,31 +1029,40 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
     typename Lane<V>::S* __restrict__ R, typename Lane<V>::S* __restrict__ S,
     typename Lane<V>::S* __restrict__ C_traj, typename Lane<V>::S* __restrict__ T_traj, const int n_rows,
     double* __restrict__ stats, const double hist_lo, const double hist_inv_w, const int n_bins,
-    unsigned long long* __restrict__ hist /* [n_steps][n_bins] or nullptr */, const int stagger) {
+    unsigned long long* __restrict__ hist /* [n_steps][n_bins] or nullptr */) {
     using L = Layout<P0, P1, P2>;
     using T = typename Lane<V>::S;
     constexpr int W = Lane<V>::W;
+    constexpr int WG_WAVES = TILE_BLOCK / 64;
     constexpr int BLOCK_MEMBERS = TILE_BLOCK * W;
     extern __shared__ unsigned int h_s[];                 // [nt][hw] packed 16-bit pairs (hist != nullptr)
-    __shared__ T drv[TILE_MAX_STEPS * DRIVE_STRIDE];
-    __shared__ V stat_tile[TILE_BLOCK / 64][STAT_STEPS * STAT_ROW];
-    __shared__ KModel<T> km_s;
+    // ONE static LDS object, the model and the drive rows FIRST: a ds_read reaches base + a 16-bit immediate offset, and the
+    // 66 KB of statistics tiles of a 1024-thread workgroup (packed lanes) pushed whatever the compiler laid out behind them
+    // past 64 KB — every model constant then needed its own address register and its own ds_read (no ds_read2 pairs):
+    // +7 LDS reads and +11 waits per step, ~17 VGPRs of addresses
+    struct TileShared {
+        KModel<T> km;
+        T drv[TILE_MAX_STEPS * DRIVE_STRIDE];
+        int next_item;
+        V stat[WG_WAVES][STAT_STEPS * STAT_ROW];
+    };
+    __shared__ TileShared sh;
+    T* const drv = sh.drv;
     {
         constexpr int NW = sizeof(KModel<T>) / sizeof(T);
         const T* src = (const T*)__builtin_amdgcn_kernarg_segment_ptr();
-        if (threadIdx.x < NW) reinterpret_cast<T*>(&km_s)[threadIdx.x] = src[threadIdx.x];
+        if (threadIdx.x < NW) reinterpret_cast<T*>(&sh.km)[threadIdx.x] = src[threadIdx.x];
     }
-    const KModel<T>& kmr = km_s;
+    const KModel<T>& kmr = sh.km;
     const int nt = t_end - t_begin;
     const int hw = (n_bins + 1) >> 1;
     const bool do_hist = hist != nullptr;
     if (do_hist)
         for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) h_s[i] = 0u;
     for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += TILE_BLOCK) drv[i] = drive[(int64_t)t_begin * DRIVE_STRIDE + i];
-    __syncthreads();
-    // experiment knob (FIVEEQ_TILE_STAGGER): the waves that share a SIMD (w, w+4, w+8, w+12) start their block loops
-    // `stagger` x 3.4 us apart so that their load / compute / store phases do not coincide (no effect: r03/ab_variants.txt)
-    for (int i = 0; i < (int)(threadIdx.x >> 8) * stagger; ++i) __builtin_amdgcn_s_sleep(127);
+#ifdef FIVEEQ_TILE_TIMING          // experiment builds (tools/tile_timing.py): when does each workgroup start and end, and where
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
 
     auto flush = [&]() {
         for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) {
@@ -1047,79 +1079,100 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
 
     const int64_t n_blocks = (n + BLOCK_MEMBERS - 1) / BLOCK_MEMBERS;
     const int64_t n_rec = (n + 63) >> 6;                                   // statistics records: one per 64 members
-    V* const tile = stat_tile[threadIdx.x >> 6];
-    int since_flush = 0;
-    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const int64_t m = (blk * TILE_BLOCK + threadIdx.x) * W;           // this lane's first member
-        const bool active = m < n;
-        const bool full = m + (W - 1) < n;
-        const int64_t mm = active ? m : 0;
-        const int64_t wave = blk * (TILE_BLOCK / 64) + (threadIdx.x >> 6);
-        const bool wave_live = stats != nullptr && wave * W < n_rec;
-        const int n_valid = (int)min((int64_t)64 * W, n - wave * 64 * W);
-        int ks = 0;
+    V* const tile = sh.stat[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    // this workgroup's member blocks are blockIdx.x, blockIdx.x + gridDim.x, ...; item = (block of the workgroup, wave slice)
+    const int my_blocks = (int)((n_blocks - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const int n_items = my_blocks * WG_WAVES;
+    const int epoch_items = do_hist ? tile_flush_blocks<V>() * WG_WAVES : n_items;      // members per epoch <= 65535
+    for (int e0 = 0; e0 < n_items; e0 += epoch_items) {
+        const int e1 = min(n_items, e0 + epoch_items);
+        if (threadIdx.x == 0) sh.next_item = e0;
+        __syncthreads();                                   // also covers the staging above (first epoch)
+        for (;;) {
+            int item = 0;
+            if (lane == 0) item = atomicAdd(&sh.next_item, 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+            if (item >= e1) break;
+            const int64_t blk = blockIdx.x + (int64_t)(item / WG_WAVES) * gridDim.x;
+            const int64_t wave = blk * WG_WAVES + (item % WG_WAVES);                    // 64-lane slice of the ensemble
+            const int64_t m = (wave * 64 + lane) * W;                                    // this lane's first member
+            const bool active = m < n;
+            const bool full = m + (W - 1) < n;
+            const int64_t mm = active ? m : 0;
+            const bool wave_live = stats != nullptr && wave * W < n_rec;
+            const int n_valid = (int)min((int64_t)64 * W, n - wave * 64 * W);
+            int ks = 0;
 
-        V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
+            V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
 #pragma unroll
-        for (int k = 0; k < L::SP; ++k) Rv[k] = load_lane<V>(R + k * ld + mm);
+            for (int k = 0; k < L::SP; ++k) Rv[k] = load_lane<V>(R + k * ld + mm);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) Sv[k] = load_lane<V>(S + k * ld + mm);
+            for (int k = 0; k < 2; ++k) Sv[k] = load_lane<V>(S + k * ld + mm);
 #pragma unroll
-        for (int k = 0; k < 3 * L::G; ++k) rr[k] = load_lane<V>(r + k * ld + mm);
+            for (int k = 0; k < 3 * L::G; ++k) rr[k] = load_lane<V>(r + k * ld + mm);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) qq[k] = load_lane<V>(q + k * ld + mm);
+            for (int k = 0; k < 2; ++k) qq[k] = load_lane<V>(q + k * ld + mm);
 
-        for (int k = 0; k < nt; ++k) {
-            const T* d = &drv[k * DRIVE_STRIDE];
-            member_step<V, L>(kmr, d, rr, qq, Rv, Sv, Cv, Tn);
-            const int row = __builtin_amdgcn_readfirstlane((int)d[7]);
-            if (row >= 0 && row < n_rows && active) {
-                if (C_traj != nullptr) {
-                    T* c = C_traj + (int64_t)row * L::G * ld + m;
+            for (int k = 0; k < nt; ++k) {
+                const T* d = &drv[k * DRIVE_STRIDE];
+                member_step<V, L>(kmr, d, rr, qq, Rv, Sv, Cv, Tn);
+                const int row = __builtin_amdgcn_readfirstlane((int)d[7]);
+                if (row >= 0 && row < n_rows && active) {
+                    if (C_traj != nullptr) {
+                        T* c = C_traj + (int64_t)row * L::G * ld + m;
 #pragma unroll
-                    for (int g = 0; g < L::G; ++g) store_lane(c + g * ld, Cv[g], full);
-                }
-                if (T_traj != nullptr) store_lane(T_traj + (int64_t)row * ld + m, Tn, full);
-            }
-            if (do_hist) {
-                if constexpr (W == 1) {
-                    if (active) tile_hist_add(&h_s[k * hw], (double)Tn, hist_lo, hist_inv_w, n_bins);
-                } else {
-                    if (active) tile_hist_add(&h_s[k * hw], (double)Tn.x, hist_lo, hist_inv_w, n_bins);
-                    if (full) tile_hist_add(&h_s[k * hw], (double)Tn.y, hist_lo, hist_inv_w, n_bins);
-                }
-            }
-            if (wave_live) {
-                tile[ks * STAT_ROW + (threadIdx.x & 63)] = Tn;
-                if (++ks == STAT_STEPS || k + 1 == nt) {
-                    const int64_t t_first = (int64_t)(t_begin + k + 1 - ks);
-                    if constexpr (W == 1) {
-                        wave_stats_flush(tile, ks, n_valid, stats + (wave * n_steps + t_first) * 4, 4);
-                    } else {
-                        wave_stats_flush(tile, ks, n_valid, stats + (2 * wave * n_steps + t_first) * 4,
-                                         2 * wave + 1 < n_rec ? stats + ((2 * wave + 1) * n_steps + t_first) * 4 : nullptr, 4);
+                        for (int g = 0; g < L::G; ++g) store_lane(c + g * ld, Cv[g], full);
                     }
-                    ks = 0;
+                    if (T_traj != nullptr) store_lane(T_traj + (int64_t)row * ld + m, Tn, full);
+                }
+                if (do_hist) {
+                    if constexpr (W == 1) {
+                        if (active) tile_hist_add(&h_s[k * hw], (double)Tn, hist_lo, hist_inv_w, n_bins);
+                    } else {
+                        if (active) tile_hist_add(&h_s[k * hw], (double)Tn.x, hist_lo, hist_inv_w, n_bins);
+                        if (full) tile_hist_add(&h_s[k * hw], (double)Tn.y, hist_lo, hist_inv_w, n_bins);
+                    }
+                }
+                if (wave_live) {
+                    tile[ks * STAT_ROW + lane] = Tn;
+                    if (++ks == STAT_STEPS || k + 1 == nt) {
+                        const int64_t t_first = (int64_t)(t_begin + k + 1 - ks);
+                        if constexpr (W == 1) {
+                            wave_stats_flush(tile, ks, n_valid, stats + (wave * n_steps + t_first) * 4, 4);
+                        } else {
+                            wave_stats_flush(tile, ks, n_valid, stats + (2 * wave * n_steps + t_first) * 4,
+                                             2 * wave + 1 < n_rec ? stats + ((2 * wave + 1) * n_steps + t_first) * 4 : nullptr, 4);
+                        }
+                        ks = 0;
+                    }
                 }
             }
-        }
-        if (active) {
+            if (active) {
 #pragma unroll
-            for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
+                for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) store_lane(S + k * ld + m, Sv[k], full);
+                for (int k = 0; k < 2; ++k) store_lane(S + k * ld + m, Sv[k], full);
+            }
         }
-        if (do_hist && ++since_flush == tile_flush_blocks<V>()) {     // uniform over the workgroup
-            __syncthreads();
+        __syncthreads();                                   // every wave is out of the epoch: counters complete, next_item free
+        if (do_hist) {
             flush();
             __syncthreads();
-            since_flush = 0;
         }
     }
+#ifdef FIVEEQ_TILE_TIMING          // the counters of the tile's LAST step row are overwritten: [workgroup] -> start, end (100 MHz), HW_ID, XCC_ID
     if (do_hist) {
         __syncthreads();
-        flush();
+        if (threadIdx.x == 0 && (blockIdx.x + 1) * 4 <= n_bins) {
+            unsigned long long* o = hist + (int64_t)(t_end - 1) * n_bins + blockIdx.x * 4;
+            o[0] = dbg_t0;
+            o[1] = wall_clock64();
+            o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        }
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------

@@ -185,12 +185,19 @@ def _row_histograms(rows, lo, hi, n_bins):
     return counts
 
 
+SELECT_CHUNK_ELEMS = 1 << 25     # elements of `rows` compared at a time in exact_percentiles (x P boolean temporaries)
+
+
 def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None, n_bins=SELECT_BINS, stats=None):
     """Exact percentiles (NumPy 'linear' definition) of rows [K, n_local] over all ranks by histogram selection:
     (1) per-row histograms between the global extrema, all-reduced; (2) the bins holding the wanted order statistics
     are read off the cumulative counts; (3) every rank counts its values BELOW the value interval of those bins (one
-    bin of margin each side) exactly, by comparison — all-reduced — and sends the values INSIDE it to the root; (4) the
-    root sorts the few candidates and reads the order statistics off at (index - below).
+    bin of margin each side) exactly, by comparison — all-reduced — and sends the values INSIDE any of a row's
+    intervals to the root (once, however many percentiles share them); (4) the root sorts the few candidates by
+    (row, value) and reads every order statistic off at (index - below) past the interval's first candidate.
+    Steps (3)-(4) are tensor operations over all K x P (row, percentile) pairs at once — blocks of rows of at most
+    SELECT_CHUNK_ELEMS values, one host synchronisation — so all-timestep exact percentiles cost K/block iterations,
+    not K x P.
     gmin/gmax [K] fp64: global extrema (from the merged moments); n_total: members over all ranks.
     Returns [K, P] fp64 on rank `dst`, None elsewhere.  `stats`, if a dict, receives bytes_to_root / allreduce_bytes."""
     dist, rank, world, exchange = _dist(group)
@@ -198,78 +205,95 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
     K, n_local = rows.shape
     P = len(percentiles)
     dev = rows.device
-    lo, hi = [float(v) for v in gmin.tolist()], [float(v) for v in gmax.tolist()]
-    counts = _row_histograms(rows, lo, hi, n_bins)
+    f64 = torch.float64
+    lo_t = gmin.to(device=dev, dtype=f64).reshape(K)
+    hi_t = gmax.to(device=dev, dtype=f64).reshape(K)
+    counts = _row_histograms(rows, lo_t.tolist(), hi_t.tolist(), n_bins)
     if exchange:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     cdf = torch.cumsum(counts, dim=1)                                              # [K, n_bins], last = n_total
     pos = [float(p) / 100.0 * (n_total - 1) for p in percentiles]
     i0 = [int(v) for v in pos]                                                     # order-statistic indices (floor)
     i1 = [min(v + 1, n_total - 1) for v in i0]
-    frac = [a - b for a, b in zip(pos, i0)]
-    want = torch.tensor([v for pair in zip(i0, i1) for v in pair], dtype=torch.int64, device=dev)
-    b = torch.searchsorted(cdf, want.reshape(1, 2 * P).expand(K, 2 * P).contiguous(), right=True).clamp_(max=n_bins - 1)
-    b = b.cpu()                                                                    # [K, 2P]: first bin with cdf > index
+    frac = torch.tensor([a - b for a, b in zip(pos, i0)], dtype=f64, device=dev)
+    i0_t = torch.tensor(i0, dtype=torch.int64, device=dev)
+    i1_t = torch.tensor(i1, dtype=torch.int64, device=dev)
+    want = torch.stack([i0_t, i1_t], dim=1).reshape(1, 2 * P)
+    b = torch.searchsorted(cdf, want.expand(K, 2 * P).contiguous(), right=True).clamp_(max=n_bins - 1)
+    b0, b1 = b[:, 0::2], b[:, 1::2]                                                # [K, P]: first bin with cdf > index
     # value interval of the candidate bins, widened by one bin on each side (the histogram back ends may put a value
-    # that sits on a bin edge on either side of it); open-ended at the extremes
-    parts, below_local = [], torch.zeros((K, P), dtype=torch.int64, device=dev)
-    sizes = []
-    for k in range(K):
-        w = (hi[k] - lo[k]) / n_bins
-        for j in range(P):
-            b0, b1 = int(b[k, 2 * j]), int(b[k, 2 * j + 1])
-            v_lo = lo[k] + (b0 - 1) * w if b0 - 1 > 0 and w > 0 else float("-inf")
-            v_hi = lo[k] + (b1 + 2) * w if b1 + 2 < n_bins and w > 0 else float("inf")
-            x = rows[k]
-            if not hi[k] > lo[k]:                    # a constant row: nothing to select, the answer is that constant
-                parts.append(x[:0])
-                sizes.append(0)
-                continue
-            below_local[k, j] = (x < v_lo).sum()
-            sel = x[(x >= v_lo) & (x < v_hi)]
-            parts.append(sel)
-            sizes.append(sel.numel())
+    # that sits on a bin edge on either side of it); open-ended at the extremes; EMPTY (+inf, +inf) for a constant row,
+    # whose answer is that constant
+    live = (hi_t > lo_t).reshape(K, 1)
+    w = ((hi_t - lo_t) / n_bins).reshape(K, 1)
+    inf = torch.full((), float("inf"), dtype=f64, device=dev)
+    v_lo = torch.where((b0 - 1 > 0) & (w > 0), lo_t.reshape(K, 1) + (b0 - 1).to(f64) * w, -inf)
+    v_hi = torch.where((b1 + 2 < n_bins) & (w > 0), lo_t.reshape(K, 1) + (b1 + 2).to(f64) * w, inf)
+    v_lo, v_hi = torch.where(live, v_lo, inf), torch.where(live, v_hi, inf)
+    # thresholds compared in the rows' dtype would move them; rows are compared in fp64 (exact for fp32 and fp64 rows)
+    below = torch.zeros((K, P), dtype=torch.int64, device=dev)
+    parts, row_sizes = [], torch.zeros(K, dtype=torch.int64, device=dev)
+    kb = max(1, min(K, SELECT_CHUNK_ELEMS // max(n_local, 1)))
+    for k0 in range(0, K, kb):
+        k1 = min(K, k0 + kb)
+        x = rows[k0:k1].to(f64).unsqueeze(2)                                       # [kb, n, 1]
+        lo_b, hi_b = v_lo[k0:k1].unsqueeze(1), v_hi[k0:k1].unsqueeze(1)            # [kb, 1, P]
+        ge = x >= lo_b
+        below[k0:k1] = n_local - ge.sum(dim=1) - torch.isnan(x).sum(dim=1)        # x < v_lo (a NaN is below nothing)
+        inside = (ge & (x < hi_b)).any(dim=2)                                      # [kb, n]: in any of the row's intervals
+        row_sizes[k0:k1] = inside.sum(dim=1)
+        parts.append(rows[k0:k1][inside])                                          # row-major: row k's candidates are contiguous
     payload = torch.cat(parts) if parts else rows.new_empty(0)
-    size_t = torch.tensor(sizes, dtype=torch.int64, device=dev)
-    below = below_local
     if exchange:
         dist.all_reduce(below, op=dist.ReduceOp.SUM, group=group)
-        all_sizes = [torch.empty_like(size_t) for _ in range(world)]
-        dist.all_gather(all_sizes, size_t, group=group)
-        all_sizes = torch.stack(all_sizes).cpu()                                   # [world, K*P]
-        longest = int(all_sizes.sum(dim=1).max().item())
+        all_sizes = [torch.empty_like(row_sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, row_sizes, group=group)
+        all_sizes = torch.stack(all_sizes)                                         # [world, K]
+        per_rank = all_sizes.sum(dim=1).cpu()
+        longest = int(per_rank.max().item())
         send = torch.cat([payload, payload.new_zeros(longest - payload.numel())])
         recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
         dist.gather(send, recv, dst=dst, group=group)
         if stats is not None:
-            stats["bytes_to_root"] = int((all_sizes.sum() - all_sizes[dst].sum()).item()) * payload.element_size()
+            stats["bytes_to_root"] = int((per_rank.sum() - per_rank[dst]).item()) * payload.element_size()
             stats["allreduce_bytes"] = counts.numel() * 8 + below.numel() * 8     # what every rank contributes
         if rank != dst:
             return None
-        offs = torch.cat([torch.zeros((world, 1), dtype=torch.int64), all_sizes.cumsum(dim=1)], dim=1)
-        cand = [torch.cat([recv[w_][offs[w_, q]:offs[w_, q + 1]] for w_ in range(world)]) for q in range(K * P)]
+        ar = torch.arange(K, device=dev)
+        cand = torch.cat([recv[w_][:int(per_rank[w_])] for w_ in range(world)])
+        cand_row = torch.cat([torch.repeat_interleave(ar, all_sizes[w_]) for w_ in range(world)])
+        seg = all_sizes.sum(dim=0)                                                 # candidates per row over all ranks
     else:
         if stats is not None:
             stats["bytes_to_root"] = 0
             stats["allreduce_bytes"] = 0
-        offs = [0]
-        for n_q in sizes:
-            offs.append(offs[-1] + n_q)
-        cand = [payload[offs[q]:offs[q + 1]] for q in range(K * P)]
-    out = torch.empty((K, P), dtype=torch.float64, device=dev)
-    below_h = below.cpu()
-    for k in range(K):
-        for j in range(P):
-            if not hi[k] > lo[k]:
-                out[k, j] = lo[k]
-                continue
-            c, _ = torch.sort(cand[k * P + j].to(torch.float64))
-            lo_i, hi_i = i0[j] - int(below_h[k, j]), i1[j] - int(below_h[k, j])
-            if not (0 <= lo_i <= hi_i < c.numel()):
-                raise RuntimeError(f"percentile selection lost its order statistic (row {k}, p={percentiles[j]}): "
-                                   f"{lo_i},{hi_i} of {c.numel()} candidates")
-            out[k, j] = c[lo_i] + (c[hi_i] - c[lo_i]) * frac[j]
-    return out
+        cand, seg = payload, row_sizes
+        cand_row = torch.repeat_interleave(torch.arange(K, device=dev), row_sizes)
+    # sort by (row, value): by value, then stably by row
+    cand = cand.to(f64)
+    order = torch.argsort(cand)
+    cand, cand_row = cand[order], cand_row[order]
+    order = torch.argsort(cand_row, stable=True)
+    cand, cand_row = cand[order], cand_row[order]
+    seg_end = torch.cumsum(seg, dim=0)
+    seg_start = seg_end - seg
+    # candidates of the row that lie below each interval (they belong to another percentile's interval)
+    skipped = torch.zeros((K, P), dtype=torch.int64, device=dev)
+    if cand.numel():
+        skipped.index_add_(0, cand_row, (cand.unsqueeze(1) < v_lo[cand_row]).to(torch.int64))
+    at0 = seg_start.reshape(K, 1) + skipped + (i0_t.reshape(1, P) - below)
+    at1 = seg_start.reshape(K, 1) + skipped + (i1_t.reshape(1, P) - below)
+    ok = (at0 >= seg_start.reshape(K, 1)) & (at0 <= at1) & (at1 < seg_end.reshape(K, 1))
+    c0 = cand[at0.clamp(0, max(cand.numel() - 1, 0))] if cand.numel() else torch.zeros((K, P), dtype=f64, device=dev)
+    c1 = cand[at1.clamp(0, max(cand.numel() - 1, 0))] if cand.numel() else torch.zeros((K, P), dtype=f64, device=dev)
+    ok &= (c0 >= v_lo) & (c1 < v_hi)                                               # both inside the interval they were sought in
+    bad = live & ~ok
+    if bool(bad.any().item()):
+        k, j = [int(v) for v in torch.nonzero(bad)[0].tolist()]
+        raise RuntimeError(f"percentile selection lost its order statistic (row {k}, p={percentiles[j]}): "
+                           f"{int(at0[k, j] - seg_start[k])},{int(at1[k, j] - seg_start[k])} of {int(seg[k])} candidates")
+    out = c0 + (c1 - c0) * frac.reshape(1, P)
+    return torch.where(live, out, lo_t.reshape(K, 1).expand(K, P))
 
 
 def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats=None):

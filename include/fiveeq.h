@@ -187,7 +187,8 @@ int fiveeq_run_ksteps_f32(const fiveeq_model *model, int64_t n_members, int64_t 
 /* TIME-TILED persistent kernel with IN-LOOP HISTOGRAMS of T: all-timestep
  * percentiles of an ensemble that stores no trajectory.  One launch per tile of k_steps steps
  * (0 = the largest tile whose LDS histogram fits, fiveeq_tile_steps_*(n_bins)); one persistent
- * 1024-thread workgroup per CU walks over member blocks and accumulates
+ * 1024-thread workgroup per CU hands its member blocks to its waves in wave-sized items (a wave takes the next item when
+ * it finishes one — a static share per wave leaves the slowest-served wave of every SIMD alone at the end) and accumulates
  *     T_hist[t][b] += #members with hist_lo + b*w <= T(t) < hist_lo + (b+1)*w,  w = (hist_hi - hist_lo)/n_bins
  * (outliers in the edge bins, NaNs skipped: the rule of fiveeq_hist_rows_*, bit for bit) in LDS,
  * flushing only non-zero bins to T_hist dev [n_steps][n_bins] uint64 (ACCUMULATED INTO: zero it

@@ -176,11 +176,11 @@ def test_new_entry_points_validate_on_the_host():
     assert tiled(0, 0.0, 1.0, 5000, p) == _capi.E_INVALID
     assert tiled(0, 1.0, 1.0, 64, p) == _capi.E_INVALID and b"lo < hi" in lib.fiveeq_last_error()
     assert tiled(0, 0.0, float("inf"), 64, p) == _capi.E_INVALID
-    assert tiled(33, 0.0, 1.0, 0, None) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
+    assert tiled(65, 0.0, 1.0, 0, None) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
     assert tiled(lib.fiveeq_tile_steps_f64(4096) + 1, 0.0, 1.0, 4096, p) == _capi.E_INVALID
     # the LDS budget: K x 8 KiB of histogram beside the kernel's statistics tiles and drive table
     assert lib.fiveeq_tile_steps_f64(4096) == 11 and lib.fiveeq_tile_steps_f32(4096) == 11
-    assert lib.fiveeq_tile_steps_f64(0) == 32 and lib.fiveeq_tile_steps_f32(1024) == 32
+    assert lib.fiveeq_tile_steps_f64(0) == 64 and lib.fiveeq_tile_steps_f32(1024) == 46 and lib.fiveeq_tile_steps_f64(1024) == 45
     assert lib.fiveeq_tile_steps_f64(-1) == 0 and lib.fiveeq_tile_steps_f32(4097) == 0
     stats = lambda rows, moments: lib.fiveeq_hist_rows_stats_f32(2, 100, 100, rows, 0.0, 1.0, 16, p, moments, None)   # noqa: E731
     assert stats(p, None) == _capi.E_INVALID and b"moments" in lib.fiveeq_last_error()

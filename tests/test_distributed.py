@@ -81,6 +81,8 @@ def _worker(rank, world, port, n_total, q):
         full = rng.normal(1.5, 0.7, size=(3, n_total))            # every rank can rebuild the global T rows
         lo, hi = shard_bounds(n_total, rank, world)
         s = gather_summary(torch.from_numpy(full[:, lo:hi].copy()), percentiles=(5.0, 50.0, 95.0))
+        close = (49.9, 50.0, 50.0, 50.1, 0.0, 100.0)              # overlapping candidate intervals, a duplicate, the extremes
+        s2 = gather_summary(torch.from_numpy(full[:, lo:hi].copy()), percentiles=close)
         x = torch.from_numpy(full[:, lo:hi].copy())
         sums = torch.stack([torch.full((3,), float(hi - lo), dtype=torch.float64), x.sum(1), (x * x).sum(1),
                             x.min(1).values, x.max(1).values], dim=1)
@@ -100,9 +102,10 @@ def _worker(rank, world, port, n_total, q):
                   and np.allclose(s["var"].numpy(), full.var(1), rtol=1e-12)
                   and s["count"].tolist() == [float(n_total)] * 3
                   and np.array_equal(s["min"].numpy(), full.min(1)) and np.array_equal(s["max"].numpy(), full.max(1)))
+            ok = ok and np.allclose(s2["percentiles"].numpy(), np.percentile(full, close, axis=1).T, rtol=1e-13)
             q.put(bool(ok and stats_ok))
         else:
-            q.put(bool(stats_ok and s["percentiles"] is None and abs(float(s["mean"][0]) - full[0].mean()) < 1e-12))
+            q.put(bool(stats_ok and s["percentiles"] is None and s2["percentiles"] is None and abs(float(s["mean"][0]) - full[0].mean()) < 1e-12))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -142,6 +145,30 @@ def test_selection_percentiles_edge_cases():
             t = torch.from_numpy(xs)
             sel = exact_percentiles(t, (0.0, 5.0, 50.0, 95.0, 100.0, 33.3), t.min(1).values.double(), t.max(1).values.double(), n)
             np.testing.assert_allclose(sel.numpy(), want, rtol=1e-14, atol=0)
+
+
+def test_selection_percentiles_many_rows_in_blocks(monkeypatch):
+    """All-timestep shape of exact_percentiles: many rows, processed in blocks of rows (the block size forced small so
+    that a block boundary falls inside the loop), percentiles so close that their candidate intervals overlap (a row's
+    candidates travel once), a constant row in the middle."""
+    from fiveeqscm_amd import distributed
+    from fiveeqscm_amd.distributed import exact_percentiles
+    rng = np.random.default_rng(11)
+    K, n = 37, 30_011
+    x = rng.normal(size=(K, n)) * rng.uniform(0.1, 5.0, size=(K, 1)) + rng.normal(size=(K, 1))
+    x[17] = -3.25
+    pct = (0.0, 5.0, 49.999, 50.0, 50.001, 95.0, 100.0)
+    want = np.percentile(x, pct, axis=1).T
+    t = torch.from_numpy(x)
+    for chunk in (1 << 25, 5 * n + 1, 1):
+        monkeypatch.setattr(distributed, "SELECT_CHUNK_ELEMS", chunk)
+        st = {}
+        got = exact_percentiles(t, pct, t.min(1).values, t.max(1).values, n, stats=st)
+        np.testing.assert_allclose(got.numpy(), want, rtol=1e-14, atol=0)
+    x32 = x.astype(np.float32)
+    t32 = torch.from_numpy(x32)
+    got = exact_percentiles(t32, pct, t32.min(1).values.double(), t32.max(1).values.double(), n)
+    np.testing.assert_allclose(got.numpy(), np.percentile(x32.astype(np.float64), pct, axis=1).T, rtol=1e-14, atol=0)
 
 
 # ---- BASELINE configs[3] rehearsed at world size 8 (CPU, gloo): every rank computes ONLY its shard of the
