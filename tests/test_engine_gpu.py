@@ -1245,7 +1245,7 @@ def test_tiled_kernel_lds_limit_is_set_once_per_instantiation(gpu):
     # (an earlier test of this session may already have prepared either instantiation: at most one new call each)
     assert counts[0] == counts[1] == counts[2] and counts[3] == counts[4] == counts[5] and counts[3] - counts[0] in (0, 1)
     small = _engine(p, N, E, store_trajectory=False, hist=(-1.0, 5.0, 512))
-    small.run(mode="tiled")                                # 32 x 1 KiB: under 48 KiB, no attribute needed
+    small.run(mode="tiled", k_steps=32)                    # 32 x 1 KiB: under 48 KiB, no attribute needed
     torch.cuda.synchronize()
     assert lib.fiveeq_tile_attr_calls() == counts[-1]
     small.close()
