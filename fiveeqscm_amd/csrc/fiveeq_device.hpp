@@ -252,23 +252,19 @@ __device__ __forceinline__ double fe_log(double x) {
     const double tail = __builtin_fma(dk, 1.90821492927058770002e-10, s * (hfsq + R));  // + k ln2_lo
     return __builtin_fma(dk, 6.93147180369123816490e-01, -((hfsq - tail) - f));          // k ln2_hi - ...
 }
+// fp32 log: ln(x) = ln2 * log2(x) with the hardware log2 (v_log_f32).  Measured on gfx950 (tools/microbench/hw_log_accuracy.hip,
+// profiles/r03/hw_log_accuracy.txt): v_log_f32 is within 1 ulp of log2(x) over [0.5, 16] AND right next to 1 (x in
+// [1, 1 + 1e-5]: 0.92 ulp of a result of ~1e-6 — no loss of relative accuracy where ln x -> 0, which is where the CO2 forcing
+// starts), and it returns exactly 0 at x = 1.  The product with ln2 = hi + lo carries the rounding error of t * hi along:
+// <= 2.1 ulp of ln(x), mean 0.55.  Five instructions per member where the frexp + division + polynomial form above took
+// twenty (fdlibm's, < 1 ulp): the forcing's log was 9 % of the fused fp32 kernel (r03/ab_variants.txt section 16).
+constexpr float F32_LN2_H = 0x1.62e430p-1f;                  // ln2 rounded to float, and what it leaves
+constexpr float F32_LN2_L = -0x1.05c610p-29f;
 __device__ __forceinline__ float fe_log(float x) {
-    float m = __builtin_amdgcn_frexp_mantf(x);
-    int k = __builtin_amdgcn_frexp_expf(x);
-    const bool low = m < 0.70710678118654752440f;
-    m = low ? m + m : m;
-    k = low ? k - 1 : k;
-    const float dk = (float)k;
-    const float f = m - 1.0f;
-    const float s = f * fe_rcp(2.0f + f);
-    const float z = s * s;
-    const float w = z * z;
-    const float t1 = w * __builtin_fmaf(w, 0.24279078841f, 0.40000972152f);               // Lg4, Lg2
-    const float t2 = z * __builtin_fmaf(w, 0.28498786688f, 0.66666662693f);               // Lg3, Lg1
-    const float R = t2 + t1;
-    const float hfsq = 0.5f * f * f;
-    const float tail = __builtin_fmaf(dk, 9.0580006145e-06f, s * (hfsq + R));             // + k ln2_lo
-    return __builtin_fmaf(dk, 6.9313812256e-01f, -((hfsq - tail) - f));                    // k ln2_hi - ...
+    const float t = __builtin_amdgcn_logf(x);
+    const float p = t * F32_LN2_H;
+    const float e = __builtin_fmaf(t, F32_LN2_H, -p);
+    return p + __builtin_fmaf(t, F32_LN2_L, e);
 }
 
 // sqrt(x) for finite normal x > 0 (a concentration): v_rsq_f64 seed, one Goldschmidt step and a
@@ -324,24 +320,10 @@ __device__ __forceinline__ float2v fe_rcp(float2v a) {
     return float2v{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
 }
 __device__ __forceinline__ float2v fe_log(float2v x) {
-    float mx = __builtin_amdgcn_frexp_mantf(x.x), my = __builtin_amdgcn_frexp_mantf(x.y);
-    int kx = __builtin_amdgcn_frexp_expf(x.x), ky = __builtin_amdgcn_frexp_expf(x.y);
-    const bool lowx = mx < 0.70710678118654752440f, lowy = my < 0.70710678118654752440f;
-    mx = lowx ? mx + mx : mx;
-    my = lowy ? my + my : my;
-    kx = lowx ? kx - 1 : kx;
-    ky = lowy ? ky - 1 : ky;
-    const float2v dk = float2v{(float)kx, (float)ky};
-    const float2v f = float2v{mx, my} - 1.0f;
-    const float2v s = f * fe_rcp(2.0f + f);
-    const float2v z = s * s;
-    const float2v w = z * z;
-    const float2v t1 = w * fe_fma(w, (float2v)0.24279078841f, (float2v)0.40000972152f);
-    const float2v t2 = z * fe_fma(w, (float2v)0.28498786688f, (float2v)0.66666662693f);
-    const float2v R = t2 + t1;
-    const float2v hfsq = 0.5f * f * f;
-    const float2v tail = fe_fma(dk, (float2v)9.0580006145e-06f, s * (hfsq + R));
-    return fe_fma(dk, (float2v)6.9313812256e-01f, -((hfsq - tail) - f));
+    const float2v t = float2v{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
+    const float2v p = t * F32_LN2_H;
+    const float2v e = fe_fma(t, (float2v)F32_LN2_H, -p);
+    return p + fe_fma(t, (float2v)F32_LN2_L, e);
 }
 __device__ __forceinline__ float2v fe_sqrt(float2v x) {
     return float2v{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};

@@ -97,7 +97,7 @@ def test_device_math_primitives_within_two_ulp(gpu):
 
 
 def test_device_math_primitives_fp32(gpu):
-    """The fp32 twins against fp64 NumPy rounded to float: <= 2 ulp (float)."""
+    """The fp32 twins against fp64 NumPy rounded to float: <= 2 ulp (float); the log (hardware log2 x ln2) <= 2.5."""
     from fiveeqscm_amd import _capi
     lib = _capi.load()
     rng = np.random.default_rng(8)
@@ -135,7 +135,12 @@ def test_device_math_primitives_fp32(gpu):
     x = np.concatenate([10.0 ** rng.uniform(-30, 30, n), rng.uniform(0.5, 4.0, n), 1.0 + 10.0 ** rng.uniform(-6, -2, 1000)])
     got, xx = probe(2, x)
     nz = np.log(xx) != 0
-    assert ulp32(got[nz], np.log(xx)[nz]).max() <= 2.0
+    u = ulp32(got[nz], np.log(xx)[nz])
+    # ln2 x the hardware log2 (v_log_f32, <= 1 ulp also next to 1): <= 2.1 ulp measured, 0.55 on average
+    assert u.max() <= 2.5 and u.mean() < 0.7, (u.max(), u.mean())
+    near = xx[nz] < 1.01
+    assert u[(xx[nz] > 1.0) & near].max() <= 2.5                       # ln next to 1 keeps RELATIVE accuracy
+    assert probe(2, np.array([1.0, 1.0]))[0].tolist() == [0.0, 0.0]    # and ln(1) is exactly 0: C = C0 gives no forcing
     got, xx = probe(3, x)
     assert ulp32(got, np.sqrt(xx)).max() <= 1.0
     got, xx = probe(4, x)
