@@ -39,6 +39,16 @@ def test_design_md_numbers_are_in_the_files_they_cite():
     cites = list(CITE.finditer(text))
     assert len(cites) >= 12, f"only {len(cites)} file-backed numbers found in DESIGN.md: the citation format changed?"
     assert len(cites) == len(LOOSE.findall(text)), "a bold number cites a .json file in a form this test cannot parse"
+    # ... and a citation that sits on the NEXT line, or further than 60 characters behind its number, is not parsed either: a
+    # bold number whose following text reaches a backticked .json path before the next bold number must be a parsed one
+    parsed = {m.start() for m in cites}
+    for m in re.finditer(r"\*\*[-+]?[0-9][0-9.,]*(?:e[-+]?[0-9]+)?\*\*", text):
+        if m.start() in parsed:
+            continue
+        tail = text[m.end():m.end() + 200].split("**")[0]
+        assert not re.search(r"\(`[A-Za-z0-9_./-]+\.json", tail), (
+            f"DESIGN.md line {text.count(chr(10), 0, m.start()) + 1}: {m.group(0)} is followed by a .json citation this test does "
+            f"not parse (put `(file.json.path)` right behind the number, on the same line)")
     cache, bad = {}, []
     for m in cites:
         path = _resolve(m["file"])
