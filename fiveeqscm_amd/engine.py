@@ -30,8 +30,11 @@ from .params import make_model, n_gas_of, pools_of
 
 _DTYPES = {torch.float64: "f64", torch.float32: "f32"}
 INFINITY_CACHE_BYTES = 256 << 20     # MI355X die-level L3 (MI355X_MICROARCH.md); sizes the chunk-major schedule
-HBM_STREAM_BYTES_PER_S = 6.7e12      # measured ceiling of the per-step kernel
-LAUNCH_BOUNDARY_S = 2.0e-6           # dependent-launch boundary on one stream (measured 1.5-2.6 us)
+# The two box-dependent figures the schedules are derived from.  The defaults are what round 1-3 measured on MI355X; another
+# box (or a future driver) can set them from the environment, or measure them with `calibrate()` below, which overwrites these
+# module attributes — engines created afterwards use the new values.
+HBM_STREAM_BYTES_PER_S = float(os.environ.get("FIVEEQ_HBM_STREAM_BYTES_PER_S", 6.7e12))    # ceiling of the per-step kernel
+LAUNCH_BOUNDARY_S = float(os.environ.get("FIVEEQ_LAUNCH_BOUNDARY_S", 2.0e-6))              # dependent-launch boundary on one stream (measured 1.5-2.6 us)
 PER_STEP_SPLIT_MIN_S = 16.0e-6       # a per-step launch is split over two streams from this much traffic time on
 PER_STEP_BLOCK = 25                  # steps enqueued per part before switching to the next part's stream
 
@@ -51,6 +54,37 @@ def _rows(x, K, N, name):
     if x.shape != (K, N):
         raise ValueError(f"{name}: shape {x.shape}, want [{K}] or [{K},{N}]")
     return x
+
+
+def calibrate(device="cuda:0", members=1_000_000, apply=True):
+    """Measure the two box-dependent figures on `device` with the per-step kernel itself and (apply=True) make them the
+    module's HBM_STREAM_BYTES_PER_S / LAUNCH_BOUNDARY_S: the dependent-launch boundary as the time per step of a 64-member
+    ensemble (nothing but launches), the streaming ceiling as algorithmic bytes per second of a per-step run of `members`
+    fp64 members, one launch per step on one stream.  Returns {"launch_boundary_s", "hbm_stream_bytes_per_s"}."""
+    import time
+
+    from . import emissions, params
+    global HBM_STREAM_BYTES_PER_S, LAUNCH_BOUNDARY_S
+    E = emissions.rcp_like_emissions(200, 3)
+    out = {}
+    for key, n in (("launch_boundary_s", 64), ("hbm_stream_bytes_per_s", int(members))):
+        p = params.sample_ensemble_shard(params.default_params("multigas"), n, device=device)
+        eng = EnsembleEngine(p, n, E, device=device, store_trajectory=False, chunk_members=None, per_step_streams=1)
+        best = None
+        for _ in range(3):
+            eng.reset_state()
+            torch.cuda.synchronize(eng.device)
+            t0 = time.perf_counter()
+            eng.run(mode="per_step")
+            torch.cuda.synchronize(eng.device)
+            dt = (time.perf_counter() - t0) / eng.n_steps
+            best = dt if best is None else min(best, dt)
+        out[key] = best if n == 64 else n * eng.bytes_per_member_step("per_step") / best
+        eng.close()
+        del eng, p
+    if apply:
+        LAUNCH_BOUNDARY_S, HBM_STREAM_BYTES_PER_S = out["launch_boundary_s"], out["hbm_stream_bytes_per_s"]
+    return out
 
 
 class EnsembleEngine:

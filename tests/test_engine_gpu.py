@@ -1348,3 +1348,23 @@ def test_per_step_parts_on_two_streams_are_bit_identical(gpu):
     t_1m = 1_000_000 * 248 / eng_mod.HBM_STREAM_BYTES_PER_S
     assert t_1m >= eng_mod.PER_STEP_SPLIT_MIN_S > 250_000 * 248 / eng_mod.HBM_STREAM_BYTES_PER_S
     small.close()
+
+
+def test_calibrate_measures_the_box_dependent_constants(gpu):
+    """engine.calibrate(): the launch boundary and the streaming ceiling the schedules are derived from, measured with the
+    per-step kernel on this box instead of taken from the baked-in MI355X figures (review: constants baked into auto_k_steps)."""
+    from fiveeqscm_amd import engine as eng_mod
+    before = (eng_mod.HBM_STREAM_BYTES_PER_S, eng_mod.LAUNCH_BOUNDARY_S)
+    got = eng_mod.calibrate(apply=False)
+    assert (eng_mod.HBM_STREAM_BYTES_PER_S, eng_mod.LAUNCH_BOUNDARY_S) == before
+    assert 0.5e-6 < got["launch_boundary_s"] < 2e-5, got
+    assert 2e12 < got["hbm_stream_bytes_per_s"] < 9e12, got
+    try:
+        eng_mod.calibrate(members=500_000)
+        assert eng_mod.LAUNCH_BOUNDARY_S != before[1] or eng_mod.HBM_STREAM_BYTES_PER_S != before[0]
+        p = prm.sample_ensemble(prm.default_params("co2"), 1000)
+        eng = _engine(p, 1000, emi.rcp_like_emissions(10, 1))
+        assert 2 <= eng.auto_k_steps() <= 16                       # a 1000-member ensemble stays launch-bound on any box
+        eng.close()
+    finally:
+        eng_mod.HBM_STREAM_BYTES_PER_S, eng_mod.LAUNCH_BOUNDARY_S = before
