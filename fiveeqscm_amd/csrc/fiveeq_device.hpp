@@ -978,7 +978,31 @@ constexpr int TILE_MAX_STEPS = 64;
 template <typename V>
 constexpr int tile_flush_blocks() { return 65535 / (TILE_BLOCK * Lane<V>::W); }      // 63 x 1024 (31 x 2048) <= 65535
 
-// bin of one value: hist_rows_kernel's rule, bit for bit
+// LDS counter increment with ONE round of wave-level aggregation.  In the first decades of a run every member's T sits in a
+// handful of bins: 64 lanes adding to the same LDS dword serialise (the first two 64-step chunks of a streamed run took
+// 1.9 and 0.8 ms in the histogram pass against 0.35 ms later).
+// So: the wave looks at the counter of its first lane; if at least 16 lanes want that same counter, ONE of them adds their
+// number and the others of the group add nothing; every other lane adds as usual.  `key` identifies the counter (the bin;
+// ~0u = this lane has nothing to count), `p` / `inc` are where and what this lane would add.  All lanes of the wave that
+// are active at the call site must call it (it is a wave-level operation on the active lanes).
+__device__ __forceinline__ void wave_lds_add(unsigned int* p, const unsigned int inc, const unsigned int key) {
+    const unsigned int k0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)key);
+    const unsigned long long same = __ballot(key == k0);
+    const int n_same = __popcll(same);
+    if (n_same >= 16) {                                               // wave-uniform
+        if (key == k0) {
+            if (k0 != ~0u && (int)(threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(p, inc * (unsigned int)n_same);
+        } else if (key != ~0u) {
+            atomicAdd(p, inc);
+        }
+    } else if (key != ~0u) {
+        atomicAdd(p, inc);
+    }
+}
+
+// bin of one value: hist_rows_kernel's rule, bit for bit.  (Plain LDS atomics here: the aggregation round above costs ~12 VALU
+// instructions per wave-step, which this VALU-bound kernel pays in time — 69.2 -> 69.9-71.6 us/step at the config-5 shard —
+// where the memory-bound passes do not.)
 __device__ __forceinline__ void tile_hist_add(unsigned int* h_row, const double v, const double lo, const double inv_w,
                                               const int n_bins) {
     if (v == v) {
@@ -1257,11 +1281,9 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
     double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;      // this pass reads every value anyway: the moments ride along
     auto count = [&](const T xv) {
         const double v = (double)xv;
-        if (v == v) {
-            const double pos = (v - lo) * inv_w;
-            const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
-            atomicAdd(&h[b], 1u);
-        }
+        const double pos = (v - lo) * inv_w;
+        const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);      // a NaN lands on 0 and is not counted
+        wave_lds_add(&h[b], 1u, v == v ? (unsigned int)b : ~0u);
         s1 += v;
         s2 = __builtin_fma(v, v, s2);
         mn = fmin(mn, v);
@@ -1324,7 +1346,8 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_bins_kernel(const int64_t n
     const int64_t m1 = min(m0 + chunk, n);
     const unsigned short* x = rows + row * ld;
     auto count = [&](const unsigned int b) {
-        if (b < (unsigned int)n_bins) atomicAdd(&h[b], 1u);
+        const bool ok = b < (unsigned int)n_bins;
+        wave_lds_add(&h[ok ? b : 0u], 1u, ok ? b : ~0u);
     };
     const bool wide = ((((uintptr_t)x) | ((uintptr_t)(ld * 2))) & 7) == 0;      // rows 8-byte aligned: 4 members per load
     int64_t m = m0 + (int64_t)threadIdx.x * 4;
