@@ -530,7 +530,7 @@ def main():
             span = k_steps or eng.tile_steps()
             kname, mode_t = "tile_kernel", "tiled"
         elif a.mode == "fused":
-            span, kname, mode_t = n_scen, "fused_kernel", "fused"
+            span, kname, mode_t = eng.fused_span_steps(n_scen), "fused_kernel", "fused"     # the engine relaunches small ensembles
         else:
             span = k_steps or eng.auto_k_steps()
             kname, mode_t = "fused_kernel", "ksteps"

@@ -37,6 +37,9 @@ HBM_STREAM_BYTES_PER_S = float(os.environ.get("FIVEEQ_HBM_STREAM_BYTES_PER_S", 6
 LAUNCH_BOUNDARY_S = float(os.environ.get("FIVEEQ_LAUNCH_BOUNDARY_S", 2.0e-6))              # dependent-launch boundary on one stream (measured 1.5-2.6 us)
 PER_STEP_SPLIT_MIN_S = 16.0e-6       # a per-step launch is split over two streams from this much traffic time on
 PER_STEP_BLOCK = 25                  # steps enqueued per part before switching to the next part's stream
+FUSED_SPAN_STEPS = 128               # mode='fused': steps per launch for ensembles of few rounds of waves (see fused_span)
+FUSED_SPAN_MAX_ROUNDS = 8.0          # ... up to this many rounds of 4 waves per SIMD
+FUSED_SPAN_MIN_ROUNDS = 0.25         # ... and from this many on
 
 
 def _rows(x, K, N, name):
@@ -93,8 +96,8 @@ class EnsembleEngine:
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
                  device=None, store_trajectory=True, output_steps=None, store_concentrations=True,
                  collect_stats=False, hist=None, hist_ring_steps="auto", hist_ring="bins",
-                 concentration_driven=False, chunk_members="auto", per_step_streams="auto", R0=None, S0=None,
-                 lib_path=None):
+                 concentration_driven=False, chunk_members="auto", per_step_streams="auto", fused_span="auto", R0=None,
+                 S0=None, lib_path=None):
         """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
         stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
         store_concentrations=False keeps only the T rows (a 100M-member fp32 run then stores 4 B instead
@@ -126,7 +129,13 @@ class EnsembleEngine:
         part's launches on its own HIP stream, so that one part's launch tail and ramp overlap the other part's kernel
         (members never interact, so nothing orders the parts against each other).  Two parts: -6.5 % per step at 1M fp64
         members (36.9 -> 34.5 us), -8 % at 0.5M, -2 % at 4M, +10 % at 0.25M (profiles/r03/two_stream_*.txt), bit-identical
-        results.  "auto": 2 when one step moves at least ~16 us of traffic, else 1; an int forces it."""
+        results.  "auto": 2 when one step moves at least ~16 us of traffic, else 1; an int forces it.
+        fused_span: mode='fused' covers the requested steps with launches of this many steps (None: one launch).  A SIMD serves
+        its oldest wave first, so the waves of a long launch finish in tiers and a launch with FEW rounds of waves ends in a
+        long tail; relaunching the same kernel resets the ages (the state crosses HBM once per span: nothing at 128 steps).
+        One launch against a relaunch every 128 steps, stats-only, fp64: -8 % at 0.1M members, -4..-5 % from 0.25M to 1.25M,
+        -3.6 % at 2M, +0.7 % at 4M (profiles/r03/relaunch_sweep.txt).  "auto": FUSED_SPAN_STEPS when the ensemble is between
+        FUSED_SPAN_MIN_ROUNDS and FUSED_SPAN_MAX_ROUNDS rounds of resident waves, else one launch.  Bit-identical either way."""
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.lib = _capi.load(lib_path)    # raises if the HIP library is not built
@@ -219,6 +228,9 @@ class EnsembleEngine:
             t_step = min(N, self.chunk_members or N) * w_ * (2 * SP + 4 * G + 7) / HBM_STREAM_BYTES_PER_S
             per_step_streams = 2 if t_step >= PER_STEP_SPLIT_MIN_S else 1
         self.per_step_streams = max(1, int(per_step_streams))
+        if fused_span not in ("auto", None) and int(fused_span) < 1:
+            raise ValueError("fused_span must be 'auto', None or a positive number of steps")
+        self.fused_span = fused_span if fused_span in ("auto", None) else int(fused_span)
         self._ps_side = []                  # side streams of the per-step parts, created on first use
         self._ps_unjoined = False           # run(..., join=False) left work on the side streams the caller's has not waited for
         self._R0 = None if R0 is None else np.asarray(R0, dtype=np.float64).reshape(SP, N)
@@ -235,6 +247,19 @@ class EnsembleEngine:
         resident = w * (sum_pools + 2 + 3 * n_gas + 2)
         c = (int(cache_bytes) // resident) // 65536 * 65536
         return c if n_members > c + c // 2 else 0
+
+    def fused_span_steps(self, n_steps):
+        """Steps per launch mode='fused' uses for a request of n_steps steps (see fused_span); n_steps = one launch."""
+        n_steps = int(n_steps)
+        if self.fused_span is None or n_steps <= 1:
+            return n_steps
+        if self.fused_span != "auto":
+            return min(self.fused_span, n_steps)
+        per_wave = 128 if self.dtype == torch.float32 and self.n_members % 2 == 0 else 64      # packed fp32 lanes carry two members
+        slots = 16 * torch.cuda.get_device_properties(self.device).multi_processor_count       # 4 waves on each of a CU's 4 SIMDs
+        rounds = -(-self.n_members // per_wave) / slots
+        # (below a quarter of a round the launches themselves weigh more than the tail: 10k members lose 3 %)
+        return min(FUSED_SPAN_STEPS, n_steps) if FUSED_SPAN_MIN_ROUNDS <= rounds <= FUSED_SPAN_MAX_ROUNDS else n_steps
 
     def auto_k_steps(self):
         """Steps per launch for mode='auto': 1 (the per-step kernel) while one step's HBM traffic hides the
@@ -435,8 +460,13 @@ class EnsembleEngine:
             elif mode == "fused" and self.T_hist is not None:
                 rc = self._run_fused_streamed_hist(t_begin, t_end, stream)
             elif mode == "fused":
-                fn = getattr(self.lib, f"fiveeq_run_fused_{self._sfx}")
-                rc = fn(*self._run_args(t_begin, t_end), self._stream(stream))
+                span = self.fused_span_steps(t_end - int(t_begin))
+                if span < t_end - int(t_begin):                  # the same kernel, relaunched every `span` steps
+                    fn = getattr(self.lib, f"fiveeq_run_ksteps_{self._sfx}")
+                    rc = fn(*self._run_args(t_begin, t_end), span, self._stream(stream))
+                else:
+                    fn = getattr(self.lib, f"fiveeq_run_fused_{self._sfx}")
+                    rc = fn(*self._run_args(t_begin, t_end), self._stream(stream))
             elif mode == "ksteps":
                 k = self.auto_k_steps() if k_steps is None else int(k_steps)
                 fn = getattr(self.lib, f"fiveeq_run_ksteps_{self._sfx}")
@@ -819,7 +849,7 @@ class EnsembleEngine:
     def bytes_per_member_step(self, mode="per_step", k_steps=None):
         """ALGORITHMIC HBM bytes per member-timestep:
         per_step:        w (2 SP + 4 G + 7)   [R,S read+write; r,q read; C,T write];
-        fused:           w (G + 1) + w (2 SP + 3 G + 6) / n_steps;
+        fused:           w (G + 1) + w (2 SP + 3 G + 6) / steps per launch (n_steps, or fused_span);
         ksteps / tiled:  w (G + 1) + w (2 SP + 3 G + 6) / k_steps  (state + parameters once per k_steps).
         With `hist=` the streamed pipelines of 'fused' and 'per_step' add the ring: T written by the step kernel and read
         back by the histogram pass, 2 w per member-step, and 'fused' then reloads state + parameters once per
@@ -833,8 +863,8 @@ class EnsembleEngine:
             if self.hist_ring == "bins":                       # 2 B written + 2 B read per member-step; wave records stay
                 ring = 4.0 + extra
             return w * (out + (2 * SP + 3 * G + 6) / max(1, min(self.hist_ring_steps, self.n_steps))) + ring
-        if mode == "fused":
-            return w * (out + (2 * SP + 3 * G + 6) / self.n_steps) + extra
+        if mode == "fused":                                     # state + parameters once per launch of fused_span_steps() steps
+            return w * (out + (2 * SP + 3 * G + 6) / self.fused_span_steps(self.n_steps)) + extra
         if mode in ("ksteps", "tiled"):
             k = k_steps or (self.auto_k_steps() if mode == "ksteps" else self.tile_steps())
             return w * (out + (2 * SP + 3 * G + 6) / max(int(k), 1)) + extra

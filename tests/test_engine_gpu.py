@@ -1368,3 +1368,38 @@ def test_calibrate_measures_the_box_dependent_constants(gpu):
         eng.close()
     finally:
         eng_mod.HBM_STREAM_BYTES_PER_S, eng_mod.LAUNCH_BOUNDARY_S = before
+
+
+def test_fused_span_relaunch_is_bit_identical(gpu, monkeypatch):
+    """mode='fused' as launches of fused_span steps (the engine's choice for ensembles of few rounds of waves: a long launch
+    ends in a long tail behind the SIMD's oldest-first arbitration) gives the bits of ONE launch: state, stored rows, wave records."""
+    from fiveeqscm_amd import engine as eng_mod
+    N, n_steps = 5000, 300
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    monkeypatch.setattr(eng_mod, "FUSED_SPAN_MIN_ROUNDS", 0.0)            # 5000 members are 2 % of a round: let "auto" relaunch them
+    for dtype in (torch.float64, torch.float32):
+        ref = _engine(p, N, E, dtype=dtype, collect_stats=True, fused_span=None)
+        assert ref.fused_span_steps(n_steps) == n_steps
+        ref.run(mode="fused")
+        for span in ("auto", 7, 128, 1000):
+            eng = _engine(p, N, E, dtype=dtype, collect_stats=True, fused_span=span)
+            want = {"auto": eng_mod.FUSED_SPAN_STEPS, 7: 7, 128: 128, 1000: n_steps}[span]
+            assert eng.fused_span_steps(n_steps) == want and eng.fused_span_steps(5) == min(want, 5)
+            eng.run(0, 100, mode="fused")
+            eng.run(100, n_steps, mode="fused")
+            torch.cuda.synchronize()
+            for name in ("R", "S", "C", "T", "T_stats"):
+                assert torch.equal(getattr(eng, name), getattr(ref, name)), (dtype, span, name)
+            assert eng.bytes_per_member_step("fused") >= ref.bytes_per_member_step("fused")
+            eng.close()
+        ref.close()
+    big = _engine(p, N, E, fused_span="auto")
+    monkeypatch.setattr(eng_mod, "FUSED_SPAN_MAX_ROUNDS", 0.0)            # an ensemble of "many rounds": one launch
+    assert big.fused_span_steps(n_steps) == n_steps
+    monkeypatch.setattr(eng_mod, "FUSED_SPAN_MAX_ROUNDS", 8.0)
+    monkeypatch.setattr(eng_mod, "FUSED_SPAN_MIN_ROUNDS", 1.0)            # ... and one too small to be worth relaunching
+    assert big.fused_span_steps(n_steps) == n_steps
+    big.close()
+    with pytest.raises(ValueError):
+        _engine(p, N, E, fused_span=0)
