@@ -185,6 +185,15 @@ def _row_histograms(rows, lo, hi, n_bins):
     return counts
 
 
+def _round_up_to(dtype, t):
+    """The smallest value of `dtype` that is >= t (fp64 tensor; infinities stay): comparing a row of that dtype against it
+    gives what comparing against t in exact arithmetic would."""
+    if dtype == torch.float64:
+        return t
+    r = t.to(dtype)
+    return torch.where(r.to(torch.float64) < t, torch.nextafter(r, torch.full_like(r, float("inf"))), r)
+
+
 SELECT_CHUNK_ELEMS = 1 << 25     # elements of `rows` compared at a time in exact_percentiles (x P boolean temporaries)
 
 
@@ -230,19 +239,33 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
     v_lo = torch.where((b0 - 1 > 0) & (w > 0), lo_t.reshape(K, 1) + (b0 - 1).to(f64) * w, -inf)
     v_hi = torch.where((b1 + 2 < n_bins) & (w > 0), lo_t.reshape(K, 1) + (b1 + 2).to(f64) * w, inf)
     v_lo, v_hi = torch.where(live, v_lo, inf), torch.where(live, v_hi, inf)
-    # thresholds compared in the rows' dtype would move them; rows are compared in fp64 (exact for fp32 and fp64 rows)
+    # The rows are compared in their OWN dtype (no fp64 copy of a 12.5M-member row): for a value x of that dtype and an fp64
+    # threshold t, x < t  <=>  x < up(t) and x >= t  <=>  x >= up(t), up(t) = the smallest value of the dtype that is >= t.
+    # One binary search per value against the row's 2P sorted thresholds gives i = #thresholds <= x; then
+    #   x < e  <=>  i <= (#thresholds < e),      so the counts below every threshold come from ONE bincount of i,
+    # and "inside any interval" is a lookup of i in a 2P+1-entry table per row.  (Boolean reductions over [rows, P, members]
+    # were tried first: torch reduces a bool tensor along an axis ten times slower than it histograms an index.)
+    t_lo, t_hi = _round_up_to(rows.dtype, v_lo), _round_up_to(rows.dtype, v_hi)
+    E2 = 2 * P
+    edges = torch.cat([t_lo, t_hi], dim=1).contiguous()                            # [K, 2P]
+    es = torch.sort(edges, dim=1).values.contiguous()
+    n_less = torch.searchsorted(es, edges, right=False)                            # [K, 2P]: thresholds strictly below each one
+    nl_lo, nl_hi = n_less[:, :P], n_less[:, P:]
+    slot = torch.arange(E2 + 1, device=dev).reshape(1, E2 + 1, 1)
+    table = ((slot > nl_lo.unsqueeze(1)) & (slot <= nl_hi.unsqueeze(1))).any(dim=2)     # [K, 2P+1]: slot i lies in some interval
     below = torch.zeros((K, P), dtype=torch.int64, device=dev)
     parts, row_sizes = [], torch.zeros(K, dtype=torch.int64, device=dev)
     kb = max(1, min(K, SELECT_CHUNK_ELEMS // max(n_local, 1)))
     for k0 in range(0, K, kb):
         k1 = min(K, k0 + kb)
-        x = rows[k0:k1].to(f64).unsqueeze(2)                                       # [kb, n, 1]
-        lo_b, hi_b = v_lo[k0:k1].unsqueeze(1), v_hi[k0:k1].unsqueeze(1)            # [kb, 1, P]
-        ge = x >= lo_b
-        below[k0:k1] = n_local - ge.sum(dim=1) - torch.isnan(x).sum(dim=1)        # x < v_lo (a NaN is below nothing)
-        inside = (ge & (x < hi_b)).any(dim=2)                                      # [kb, n]: in any of the row's intervals
-        row_sizes[k0:k1] = inside.sum(dim=1)
-        parts.append(rows[k0:k1][inside])                                          # row-major: row k's candidates are contiguous
+        x = rows[k0:k1]
+        i = torch.searchsorted(es[k0:k1], x, right=True)                           # [kb, n] in 0..2P; a NaN sorts last (2P): in no
+        i += (torch.arange(k1 - k0, device=dev) * (E2 + 1)).unsqueeze(1)           # interval and below nothing
+        c = torch.bincount(i.flatten(), minlength=(k1 - k0) * (E2 + 1)).reshape(k1 - k0, E2 + 1)
+        below[k0:k1] = torch.cumsum(c, dim=1).gather(1, nl_lo[k0:k1])              # members with i <= #thresholds < lo_j
+        inside = table[k0:k1].flatten()[i]                                          # [kb, n]
+        row_sizes[k0:k1] = torch.bincount(i.flatten()[inside.flatten()] // (E2 + 1), minlength=k1 - k0)
+        parts.append(x[inside])                                                     # row-major: row k's candidates are contiguous
     payload = torch.cat(parts) if parts else rows.new_empty(0)
     if exchange:
         dist.all_reduce(below, op=dist.ReduceOp.SUM, group=group)
