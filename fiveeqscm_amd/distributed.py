@@ -66,13 +66,31 @@ def local_moments(x):
     M2 = sum(x^2) - n mean^2.  The subtraction costs log10(mean^2 / var) digits of the variance (one digit for an
     ensemble temperature row; the kernels' own per-wave records use the same two sums)."""
     n = x.shape[1]
-    s1 = x.sum(dim=1, dtype=torch.float64)
-    s2 = torch.linalg.vector_norm(x, ord=2, dim=1, dtype=torch.float64) ** 2
+    s1 = _by_rows(x, lambda v, d: v.sum(dim=d, dtype=torch.float64), lambda v, d: v.sum(dim=d))
+    s2 = _by_rows(x, lambda v, d: torch.linalg.vector_norm(v, ord=2, dim=d, dtype=torch.float64) ** 2, lambda v, d: v.sum(dim=d))
     mean = s1 / n
     m2 = (s2 - n * mean * mean).clamp_min(0.0)
     cnt = torch.full_like(mean, float(n))
-    return torch.stack([cnt, mean, m2, x.min(dim=1).values.to(torch.float64), x.max(dim=1).values.to(torch.float64)],
-                       dim=1)
+    mn = _by_rows(x, lambda v, d: v.amin(dim=d), lambda v, d: v.amin(dim=d)).to(torch.float64)
+    mx = _by_rows(x, lambda v, d: v.amax(dim=d), lambda v, d: v.amax(dim=d)).to(torch.float64)
+    return torch.stack([cnt, mean, m2, mn, mx], dim=1)
+
+
+_ROW_PIECE = 8192
+
+
+def _by_rows(x, first, second):
+    """Reduce x [K, n] along its rows in two stages — pieces of 8192 members, then the pieces — because torch reduces a long
+    axis into a HANDFUL of outputs an order of magnitude slower than into many (3 rows of 12.5M members: 14 ms for the four
+    moments in one stage, 1 ms in two).  `first(v, dim)` reduces the members of a piece, `second(v, dim)` combines pieces."""
+    K, n = x.shape
+    if n <= 4 * _ROW_PIECE:
+        return first(x, 1)
+    m = (n // _ROW_PIECE) * _ROW_PIECE
+    parts = [first(x[:, :m].reshape(K, n // _ROW_PIECE, _ROW_PIECE), 2)]
+    if n > m:
+        parts.append(first(x[:, m:], 1).reshape(K, 1))
+    return second(torch.cat(parts, dim=1), 1)
 
 
 def merge_moments(parts):
