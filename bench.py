@@ -552,16 +552,17 @@ def main():
         achieved = A * n_local / k_avg / 1e9
         roofline = {"bound": "fp64-valu" if a.dtype == "f64" else "fp32-valu", "unit": "wave-instr/s",
                     "achieved": None, "peak": valu_peak, "frac": None, "traffic": None,
-                    "kernel": f"fiveeq::{kname}<{tname if kname == 'tile_kernel' else lname},{pools3}>", "steps_per_launch": span,
+                    "kernel": f"fiveeq::{kname}<{lname},{pools3}>", "steps_per_launch": span,
                     "algorithmic_bytes_per_member_step": A, "members_per_launch": n_local,
                     "hbm_GBs_of_algorithmic_bytes": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
                     "avg_step_us_in_kernel": k_avg * 1e6, "launches_timed": int(samples.size) * reps,
                     "timed_as": f"{samples.size} whole {n_scen}-step scenario passes from the initial state",
                     "note": "time-fused family: state stays in registers, the kernel is bound by VALU issue, not HBM; "
                             "frac = VALU wave-instructions per second / (1024 SIMDs x 2.4 GHz / cycles per instruction)."}
-        kkey = f"fused:{vtag}:{pools3}" if kname == "fused_kernel" else f"tile:{a.dtype}:{pools3}"
+        kkey = f"{'fused' if kname == 'fused_kernel' else 'tile'}:{vtag}:{pools3}"      # the tiled kernel packs its fp32 lanes too
         if kname == "tile_kernel":
-            members_per_wave = 64
+            roofline["note"] += ("  The tiled kernel's instruction count in profiles/valu.json was taken WITH its 4096-bin in-loop "
+                                 "histogram at 8 steps per tile: without the histogram, or with longer tiles, it executes fewer.")
     # VALU issue: instructions per wave-step from the committed SQ-counter pass (profiles/valu.json, produced by
     # tools/collect_profiles.sh with rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ...), times the waves this bench ran
     valu = load_profile_json("valu.json", kkey)
