@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FIVEEQ_LIB_PATH selects another build of the same library (e.g. the host-sanitizer build of tools/sanitize_host.sh)
 LIB_PATH = os.environ.get("FIVEEQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_GAS = 3
 MAX_POOLS = 4
 N_BOX = 2
@@ -71,6 +71,8 @@ _STEP_ARGS = [_mp, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p,
 SIGNATURES = {
     "fiveeq_abi_version": (ctypes.c_int, []),
     "fiveeq_last_error": (ctypes.c_char_p, []),
+    "fiveeq_source_hash": (ctypes.c_char_p, []),
+    "fiveeq_build_flags": (ctypes.c_char_p, []),
     "fiveeq_sizeof_model": (ctypes.c_int64, []),
     "fiveeq_layout_supported": (ctypes.c_int, [_i32, ctypes.POINTER(_i32)]),
     "fiveeq_stats_waves": (ctypes.c_int64, [_i64]),
@@ -115,6 +117,21 @@ SIGNATURES = {
 }
 
 _lib = None
+SOURCES = (os.path.join(_HERE, "csrc", "fiveeq_capi.hip"), os.path.join(_HERE, "csrc", "fiveeq_device.hpp"),
+           os.path.join(os.path.dirname(_HERE), "include", "fiveeq.h"))
+
+
+def source_hash():
+    """sha256 (hex) of the library's three sources as they lie in this tree, concatenated in SOURCES order — what
+    csrc/Makefile stamps into the library; None when the tree carries no sources (an installed binary)."""
+    import hashlib
+    if not all(os.path.exists(p) for p in SOURCES):
+        return None
+    h = hashlib.sha256()
+    for p in SOURCES:
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def load(path=None):
@@ -149,9 +166,21 @@ def load(path=None):
     if lib.fiveeq_sizeof_model() != ctypes.sizeof(Model):
         raise ImportError(f"{lib_path}: sizeof(fiveeq_model)={lib.fiveeq_sizeof_model()} but the ctypes "
                           f"mirror is {ctypes.sizeof(Model)} bytes")
+    # The library must have been compiled from the sources lying next to this file: a prebuilt .so that travelled to
+    # another box, or survived a source edit, is refused instead of tested.  (FIVEEQ_ALLOW_STALE_LIB=1: experiment
+    # variants built from patched sources, tools/ only.)
+    want, got_hash = source_hash(), (lib.fiveeq_source_hash() or b"").decode()
+    if want is not None and got_hash != want and os.environ.get("FIVEEQ_ALLOW_STALE_LIB") != "1":
+        raise ImportError(f"{lib_path} was built from other sources (library {got_hash[:16]}, tree {want[:16]}): "
+                          "run `make -C fiveeqscm_amd/csrc`")
     if path is None:
         _lib = lib
     return lib
+
+
+def build_flags(lib=None):
+    """Experiment knobs the loaded library was compiled with ('' for the product build)."""
+    return ((lib or load()).fiveeq_build_flags() or b"").decode().strip()
 
 
 def check(lib, rc):

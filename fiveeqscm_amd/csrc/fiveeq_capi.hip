@@ -528,6 +528,40 @@ int plan_create(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, in
 extern "C" {
 
 int fiveeq_abi_version(void) { return FIVEEQ_ABI_VERSION; }
+#ifndef FIVEEQ_SOURCE_HASH
+#define FIVEEQ_SOURCE_HASH "unstamped"      // built outside csrc/Makefile: the Python binding refuses such a library
+#endif
+const char* fiveeq_source_hash(void) { return FIVEEQ_SOURCE_HASH; }
+#define FIVEEQ_STR2(x) #x
+#define FIVEEQ_STR(x) FIVEEQ_STR2(x)
+const char* fiveeq_build_flags(void) {
+    return ""
+#ifdef FIVEEQ_FUSED_TIMING
+           " FIVEEQ_FUSED_TIMING"
+#endif
+#ifdef FIVEEQ_TILE_TIMING
+           " FIVEEQ_TILE_TIMING"
+#endif
+#ifdef FIVEEQ_STEP_WAVES
+           " FIVEEQ_STEP_WAVES=" FIVEEQ_STR(FIVEEQ_STEP_WAVES)
+#endif
+#if FIVEEQ_FUSED_DYN_LDS != 0
+           " FIVEEQ_FUSED_DYN_LDS=" FIVEEQ_STR(FIVEEQ_FUSED_DYN_LDS)
+#endif
+#if FIVEEQ_BLOCK != 256
+           " FIVEEQ_BLOCK=" FIVEEQ_STR(FIVEEQ_BLOCK)
+#endif
+#if FIVEEQ_STEP_BLOCK != 64
+           " FIVEEQ_STEP_BLOCK=" FIVEEQ_STR(FIVEEQ_STEP_BLOCK)
+#endif
+#if FIVEEQ_TILE_BLOCK != 1024
+           " FIVEEQ_TILE_BLOCK=" FIVEEQ_STR(FIVEEQ_TILE_BLOCK)
+#endif
+#if FIVEEQ_FUSED_CHUNK != 125
+           " FIVEEQ_FUSED_CHUNK=" FIVEEQ_STR(FIVEEQ_FUSED_CHUNK)
+#endif
+        ;
+}
 const char* fiveeq_last_error(void) { return g_err; }
 int64_t fiveeq_sizeof_model(void) { return (int64_t)sizeof(fiveeq_model); }
 int64_t fiveeq_stats_waves(int64_t n_members) { return n_members < 1 ? 0 : (n_members + 63) / 64; }

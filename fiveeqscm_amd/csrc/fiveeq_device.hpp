@@ -40,6 +40,21 @@
 #define FIVEEQ_FUSED_CHUNK 125    // drive-table steps staged into LDS per refill (fused kernel)
 #endif
 
+// Experiment hooks (wave / workgroup timestamps): empty in the product.  The code behind them lives in
+// tools/variants/fiveeq_timing_hooks.hpp and is compiled in only by -DFIVEEQ_FUSED_TIMING / -DFIVEEQ_TILE_TIMING builds,
+// which fiveeq_build_flags() reports (tests/test_capi_cpu.py asserts the shipped library has none).
+#if defined(FIVEEQ_FUSED_TIMING) || defined(FIVEEQ_TILE_TIMING)
+#include "../../tools/variants/fiveeq_timing_hooks.hpp"
+#endif
+#ifndef FIVEEQ_HOOK_FUSED_BEGIN
+#define FIVEEQ_HOOK_FUSED_BEGIN
+#define FIVEEQ_HOOK_FUSED_END
+#endif
+#ifndef FIVEEQ_HOOK_TILE_BEGIN
+#define FIVEEQ_HOOK_TILE_BEGIN
+#define FIVEEQ_HOOK_TILE_END
+#endif
+
 namespace fiveeq {
 
 constexpr int MAX_GAS = 3;
@@ -859,9 +874,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const int n_valid = (int)min((int64_t)64 * W, n - wave * 64 * W);               // members of this wave (<= 0: none)
     int ks = 0;                                                                      // steps parked in the tile
 
-#ifdef FIVEEQ_FUSED_TIMING          // experiment builds (tools/fused_timing.py): when and where does each wave run
-    const unsigned long long dbg_t0 = wall_clock64();
-#endif
+    FIVEEQ_HOOK_FUSED_BEGIN
     V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
     if constexpr (INV) {
 #pragma unroll
@@ -926,15 +939,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
             }
         }
     }
-#ifdef FIVEEQ_FUSED_TIMING          // the wave's statistics record of the LAST step is overwritten: start, end (100 MHz), HW_ID, XCC_ID
-    if (wave_live && (threadIdx.x & 63) == 0) {
-        double* o = stats + ((int64_t)W * wave * n_steps + (t_end - 1)) * 4;
-        o[0] = (double)dbg_t0;
-        o[1] = (double)wall_clock64();
-        o[2] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-        o[3] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
-    }
-#endif
+    FIVEEQ_HOOK_FUSED_END
     if (active) {
 #pragma unroll
         for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
@@ -1065,9 +1070,7 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
     if (do_hist)
         for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) h_s[i] = 0u;
     for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += TILE_BLOCK) drv[i] = drive[(int64_t)t_begin * DRIVE_STRIDE + i];
-#ifdef FIVEEQ_TILE_TIMING          // experiment builds (tools/tile_timing.py): when does each workgroup start and end, and where
-    const unsigned long long dbg_t0 = wall_clock64();
-#endif
+    FIVEEQ_HOOK_TILE_BEGIN
 
     auto flush = [&]() {
         for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) {
@@ -1166,18 +1169,7 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
             __syncthreads();
         }
     }
-#ifdef FIVEEQ_TILE_TIMING          // the counters of the tile's LAST step row are overwritten: [workgroup] -> start, end (100 MHz), HW_ID, XCC_ID
-    if (do_hist) {
-        __syncthreads();
-        if (threadIdx.x == 0 && (blockIdx.x + 1) * 4 <= n_bins) {
-            unsigned long long* o = hist + (int64_t)(t_end - 1) * n_bins + blockIdx.x * 4;
-            o[0] = dbg_t0;
-            o[1] = wall_clock64();
-            o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-            o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        }
-    }
-#endif
+    FIVEEQ_HOOK_TILE_END
 }
 
 // ---------------------------------------------------------------------------------

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   7
+#define FIVEEQ_ABI_VERSION   8
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
@@ -111,6 +111,13 @@ typedef struct fiveeq_model {
 /* new — library identification */
 int         fiveeq_abi_version(void);
 const char *fiveeq_last_error(void);
+/* new — sha256 (hex) of the three sources this library was compiled from, concatenated in this order:
+ * fiveeq_capi.hip, fiveeq_device.hpp, include/fiveeq.h — stamped by csrc/Makefile ("unstamped" otherwise).  A binding that
+ * sits next to those sources recomputes it and refuses a library built from other text (fiveeqscm_amd/_capi.py). */
+const char *fiveeq_source_hash(void);
+/* new — the experiment knobs this library was compiled with (-DFIVEEQ_FUSED_TIMING, -DFIVEEQ_STEP_WAVES=..., non-default
+ * block sizes ...), space-separated; "" for the product build. */
+const char *fiveeq_build_flags(void);
 /* new — sizeof(fiveeq_model) as the library was compiled, for binding self-checks */
 int64_t     fiveeq_sizeof_model(void);
 /* new — 1 if (n_gas, n_pools[]) has a compiled kernel, else 0 */

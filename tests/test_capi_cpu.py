@@ -30,6 +30,29 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert [lib.fiveeq_stats_waves(n) for n in (0, 1, 64, 65, 1_000_000)] == [0, 1, 1, 2, 15625]
 
 
+def test_shipped_library_is_stamped_with_its_sources_and_has_no_experiment_knobs():
+    """csrc/Makefile stamps the sha256 of (fiveeq_capi.hip, fiveeq_device.hpp, fiveeq.h) into the library; the binding
+    recomputes it from the tree.  The product build carries no experiment flag (timing hooks, occupancy caps, block shapes)."""
+    lib = _capi.load()
+    assert lib.fiveeq_source_hash().decode() == _capi.source_hash() and len(_capi.source_hash()) == 64
+    assert _capi.build_flags(lib) == ""
+    with open(os.path.join(ROOT, "fiveeqscm_amd", "csrc", "fiveeq_device.hpp")) as fh:
+        text = fh.read()
+    assert "wall_clock64" not in text and "s_getreg" not in text, "experiment code belongs in tools/variants/"
+
+
+def test_a_library_built_from_other_sources_is_refused(tmp_path, monkeypatch):
+    """Same binary, but the tree's sources differ from what it was stamped with: load() must raise, not test a stale .so."""
+    import shutil
+    copy = tmp_path / "libfiveeq_hip.so"
+    shutil.copy(_capi.LIB_PATH, copy)
+    monkeypatch.setattr(_capi, "source_hash", lambda: "0" * 64)
+    with pytest.raises(ImportError, match="built from other sources"):
+        _capi.load(str(copy))
+    monkeypatch.setenv("FIVEEQ_ALLOW_STALE_LIB", "1")                     # tools/ only: variants of patched sources
+    assert _capi.load(str(copy)).fiveeq_abi_version() == _capi.ABI_VERSION
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(ImportError, match="no CPU fallback"):
         _capi.load(str(tmp_path / "libfiveeq_hip.so"))
