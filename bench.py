@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for every N: called plainly with N > 1, this script starts the launcher form itself as a CHILD process
+before it imports torch or touches a GPU (`_self_launch`), relays the child's one line and exits with its code.
+
 A "step" is ONE MODEL TIMESTEP of the whole ensemble = one launch of the per-timestep HIP kernel
 (fiveeq_step_f64, include/fiveeq.h) on each GPU.  Workload (BASELINE.json configs[2], the
 largest single-GPU configuration and the one the roofline target is quoted for): 1,000,000
@@ -14,12 +17,21 @@ every rank draws exactly its own members on its own GPU), state and parameters r
 trajectory rows written every step.  Timesteps cycle through the 750-step scenario (t = k mod 750); the
 default K + W = 750 is exactly one scenario pass.
 
-Rank 0 prints ONE JSON line.  `value` = (members on all GPUs) x K / max-over-ranks wall time of
-the K timed steps.  `roofline` prices the kernel of the chosen --mode: the per-step kernel against the
+Rank 0 prints ONE JSON line.  `value` = (members on all GPUs) x K / the K-step block time, MAX over ranks: the block is
+clocked once on the wall clock (barrier, device sync, clock, K steps, drain, clock: `timing.first_block_ms_per_step`) and then
+repeated back to back for --timed-s (6.5) seconds of device time, HIP event to HIP event; the MEDIAN block is reported.
+`timing.host_enqueue_us_per_step` / `host_share` say how long the rank's host thread needs to enqueue a step with all ranks
+enqueuing at once.  `roofline` prices the kernel of the chosen --mode: the per-step kernel against the
 8 TB/s HBM peak with the ALGORITHMIC bytes A = w(2 SP + 4 G + 7) = 248 B per member-step (plus the same
 kernel on an ensemble far beyond the Infinity Cache, `hbm_resident`, and its fp64 VALU issue fraction);
 the fused / K-step kernels with their own A and bound "fp64-valu".  `cpu_baseline` times the CPU oracle
-(plain-C port, OpenMP) on this box's host cores on a bounded sample (rank 0, N=1 only).
+(NumPy, one process per usable core, and the plain-C port under OpenMP) on this box's host cores on a bounded sample
+(rank 0, N=1 only) BEFORE the GPU is touched, so that the GPU work of the run is one contiguous window.
+
+N > 1: one process per GPU; time-stepping needs no collective.  The barriers around the clocked region and the MAX of the
+clocked times go over a gloo control group (host scalars); the end-of-run summary exchange — the only collective that moves
+ensemble data — goes over RCCL, LAST, with the line already complete and a watchdog thread beside it: a failed or hung
+exchange costs the line its `summary` (-> {"error": ...}, non-zero exit), never its measurement.
 """
 import argparse
 import ctypes
@@ -51,6 +63,57 @@ def _numpy_worker(argv):
 if len(sys.argv) > 1 and sys.argv[1] == "--numpy-worker":
     _numpy_worker(sys.argv[2:])
     sys.exit(0)
+
+
+
+def _self_launch():
+    """Plain `python bench.py --gpus N ...` with N > 1 and no launcher environment (the way the driver calls --gpus 1):
+    this process — BEFORE it imports torch or touches a GPU — starts
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>
+    as a CHILD process (its own session, so that a timeout can end the whole group), relays the child's stdout (rank 0's
+    one JSON line) and stderr, and exits with the child's code.  It never initialises the GPU itself: no exec from a
+    process that has.  The explicit launcher form (WORLD_SIZE / RANK in the environment) does not come through here."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ or "--numpy-worker" in sys.argv:
+        return
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--launch-timeout-s", type=float, default=570.0)
+    known, _ = ap.parse_known_args()
+    if known.gpus <= 1:
+        return
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={known.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this host driver
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)      # stdout / stderr inherited: the line passes through
+    try:
+        rc = proc.wait(timeout=known.launch_timeout_s)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {known.gpus}-rank child job exceeded --launch-timeout-s {known.launch_timeout_s:.0f}: "
+              "ending its process group", file=sys.stderr, flush=True)
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+            proc.wait(timeout=15)
+        except Exception:  # noqa: BLE001
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except Exception:  # noqa: BLE001
+                pass
+        rc = 124
+    except KeyboardInterrupt:
+        os.killpg(proc.pid, signal.SIGTERM)
+        rc = 130
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    _self_launch()
 
 import torch  # noqa: E402
 
@@ -94,9 +157,16 @@ def parse():
     ap.add_argument("--hbm-resident-members", type=int, default=8_000_000)
     ap.add_argument("--cpu-sample-members", type=int, default=1_500_000)
     ap.add_argument("--kernel-batches", type=int, default=5, help="event-timed batches of 100 launches for roofline")
-    ap.add_argument("--min-timed-ms", type=float, default=20.0,
-                    help="a K-step block shorter than this is repeated and the MEDIAN block reported (0: time one block)")
-    ap.add_argument("--max-repeats", type=int, default=101)
+    ap.add_argument("--timed-s", type=float, default=6.5,
+                    help="device seconds to clock: the K-step block is repeated back to back until this much device time has "
+                         "been clocked and the MEDIAN block is reported (0: time ONE block on the wall clock)")
+    ap.add_argument("--max-repeats", type=int, default=20001)
+    ap.add_argument("--dist-timeout-s", type=float, default=90.0, help="timeout of every process group (init and collectives)")
+    ap.add_argument("--summary-watchdog-s", type=float, default=60.0,
+                    help="N > 1: if the end-of-run exchange has not returned after this long, rank 0 prints the (complete) "
+                         "line with summary.error and the job exits non-zero")
+    ap.add_argument("--launch-timeout-s", type=float, default=570.0,
+                    help="plain `--gpus N` form only: the self-started child job is ended after this long")
     ap.add_argument("--numpy-baseline", action="store_true",
                     help="add SURVEY 8d's NumPy legs to cpu_baseline: N = 1e5 on one core and on one process per usable "
                          "core, CO2-only and multi-gas (baseline only; adds ~1-2 min)")
@@ -262,15 +332,41 @@ def load_profile_json(name, key):
         return None
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block (native libraries that print to stdout do not go through sys.stdout)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit(f"--gpus {a.gpus} needs the torch.distributed.run launcher (see the docstring)")
+        if world == 1 and a.gpus > 1:       # only reachable when bench.main() is called from other code: the script self-launches
+            sys.exit(f"--gpus {a.gpus} needs WORLD_SIZE / RANK / LOCAL_RANK from a launcher (run bench.py as a script)")
         a.gpus = world
+    kind, G, per_gpu, desc = WORKLOADS[a.workload]
+    per_gpu = a.members or per_gpu
+    n_total = per_gpu * world
+    n_scen = 750
+
+    # ---- CPU baseline FIRST (rank 0 of a one-GPU run only): the GPU has not been touched yet, so everything after this leg
+    # is one contiguous window of GPU work for whoever samples the card from outside ------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(kind, G, a.cpu_sample_members, n_scen, numpy_legs=a.numpy_baseline)
+
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # FIVEEQ_BENCH_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks
     # (ranks share devices, the summary exchange goes through host memory); the default is RCCL.
@@ -278,30 +374,34 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
-    dist = None
-    # FIVEEQ_BENCH_FORCE_DIST=1: build the process group and run every collective of the N > 1 path (barriers, the MAX
+    dist, data_group = None, None
+    # FIVEEQ_BENCH_FORCE_DIST=1: build the process groups and run every collective of the N > 1 path (barriers, the MAX
     # of the block times, the summary exchange) in a ONE-rank job too — RCCL first contact for this file on a one-GPU box.
     force_dist = world == 1 and os.environ.get("FIVEEQ_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
+        # TWO process groups.  CONTROL plane (default group): gloo over 127.0.0.1 — the barriers around the timed region and
+        # the MAX of the block times, host scalars only.  DATA plane: RCCL ("nccl" on ROCm) — the end-of-run summary
+        # exchange, the only collective that moves ensemble data; its communicator is created by its first collective, which
+        # happens AFTER the measurement and under a watchdog.  Whatever RCCL does on first contact across xGMI (an exception,
+        # a hang) can therefore cost the line its `summary`, never its measurement.  Every group has a timeout.
+        from datetime import timedelta
+
         import torch.distributed as dist
         if force_dist:
             for key, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29513"), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(key, val)
             from fiveeqscm_amd.distributed import force_collectives
             force_collectives(True)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)    # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(backend)
+        tmo = timedelta(seconds=a.dist_timeout_s)
+        with _stdout_to_stderr():          # gloo announces its connections on STDOUT: the one line must stay the only one
+            dist.init_process_group("gloo", timeout=tmo)
+            data_group = dist.new_group(backend="nccl", timeout=tmo) if backend == "nccl" else dist.group.WORLD
+            dist.barrier()
 
     from fiveeqscm_amd import emissions, params
     from fiveeqscm_amd.distributed import gather_summary, shard_bounds
     from fiveeqscm_amd.engine import EnsembleEngine
 
-    kind, G, per_gpu, desc = WORKLOADS[a.workload]
-    per_gpu = a.members or per_gpu
-    n_total = per_gpu * world
-    n_scen = 750
     dtype = torch.float64 if a.dtype == "f64" else torch.float32
     k_steps = a.k_steps or None
 
@@ -317,7 +417,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier()                                       # control plane (gloo)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -325,10 +425,10 @@ def main():
         torch.cuda.synchronize(dev)
 
     def max_over_ranks(values):
-        """Element-wise MAX over the ranks of a list of floats (a collective, never inside a clocked region)."""
+        """Element-wise MAX over the ranks of a list of floats (a control-plane collective, never inside a clocked region)."""
         if dist is None:
             return [float(v) for v in values]
-        tt = torch.tensor(values, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tt = torch.tensor(values, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return [float(v) for v in tt.tolist()]
 
@@ -345,10 +445,11 @@ def main():
     # ---- warm-up, then EXACTLY K timed steps ------------------------------------------------------
     # The clocked region holds this rank's K steps and nothing else: barrier (all ranks start together), device
     # synchronise, clock, K steps, device synchronise, clock.  No collective sits inside it — at 20 steps the region is
-    # under a millisecond and a barrier would be a tenth of it.  The per-rank times are MAX-reduced afterwards.  A block
-    # shorter than --min-timed-ms is repeated (same K, the scenario index keeps cycling) and the MEDIAN block is what
-    # `value` and `ms_per_step` report, so that a 20-step call is not one sub-millisecond sample; `timed_repeats` says
-    # how many blocks were clocked and `first_block_ms_per_step` keeps the single-sample figure.
+    # under a millisecond and a barrier would be a tenth of it.  The per-rank times are MAX-reduced afterwards.  The block
+    # is then REPEATED back to back (same K, the scenario index keeps cycling) until --timed-s of device time has been
+    # clocked, and the MEDIAN block is what `value` and `ms_per_step` report: a 20-step call is not one sub-millisecond
+    # sample, and the card is visibly busy for seconds to anything that samples it from outside.  `timed_repeats` says how
+    # many blocks were clocked and `first_block_ms_per_step` keeps the single-sample figure.
     t_idx = run_steps(eng, 0, a.warmup, a.mode, k_steps)
 
     def prepare_graphs(t_from, k):
@@ -363,7 +464,8 @@ def main():
         os._exit(17)
 
     def timed_block(t_from):
-        """One K-step block on the wall clock: barrier, device sync, clock, K steps, drained stream, clock."""
+        """One K-step block on the wall clock: barrier, device sync, clock, K steps, drained stream, clock.  Also returns
+        the host's share of it: the time until the last launch call had returned."""
         if a.mode == "graph":                  # instantiate the block's graphs outside the timing
             prepare_graphs(t_from % n_scen, a.steps)
         torch.cuda.synchronize(dev)
@@ -372,25 +474,26 @@ def main():
         done = torch.cuda.Event()
         t0 = time.perf_counter()
         t_next = run_steps(eng, t_from, a.steps, a.mode, k_steps)
+        t_enq = time.perf_counter()
         done.record()                          # on the launch stream, behind the K-th step
         while not done.query():                # spin: a blocking synchronise would add its wake-up latency to the block
             pass
         t1 = time.perf_counter()
         torch.cuda.synchronize(dev)
-        return t1 - t0, t_next
+        return t1 - t0, t_next, t_enq - t0
 
-    first, t_idx = timed_block(t_idx)
+    first, t_idx, _ = timed_block(t_idx)
     first_max = max_over_ranks([first])[0]
     repeats, blocks, wall_all = 1, [first], None
-    if a.min_timed_ms > 0 and first_max * 1e3 < a.min_timed_ms:
-        # A short block (the driver's 20-step call is 0.75 ms) is repeated, and the repeats run BACK TO BACK: one barrier +
-        # device sync before the first, then R x K steps enqueued with a HIP event on the launch stream at every block
-        # boundary, one drain at the end.  Block i = event i -> event i+1 on the device's own clock, so a block holds its K
-        # steps and nothing else — no idle-stream launch latency, no host wake-up — exactly what K steps cost inside a long
-        # run.  The wall clock around all R blocks is kept beside it as the cross-check.
-        repeats = int(min(max(a.max_repeats, 1), -(-a.min_timed_ms * 1e-3 // max(first_max, 1e-6)))) | 1     # odd
+    if a.timed_s > 0 and first_max < a.timed_s:
+        # The repeats run BACK TO BACK: one barrier + device sync before the first, then R x K steps enqueued with a HIP
+        # event on the launch stream at every block boundary, one drain at the end.  Block i = event i -> event i+1 on the
+        # device's own clock, so a block holds its K steps and nothing else — no idle-stream launch latency, no host
+        # wake-up — exactly what K steps cost inside a long run.  The wall clock around all R blocks is kept beside it as
+        # the cross-check.  (The host runs ahead of the device until the HIP queue is full and is then paced by it.)
+        repeats = int(min(max(a.max_repeats, 1), -(-a.timed_s // max(first_max, 1e-6)))) | 1     # odd
         if a.mode == "graph":
-            prepare_graphs(t_idx % n_scen, a.steps * repeats)
+            prepare_graphs(t_idx % n_scen, a.steps * min(repeats, -(-n_scen // a.steps) + 1))
         torch.cuda.synchronize(dev)
         barrier()
         torch.cuda.synchronize(dev)
@@ -418,44 +521,56 @@ def main():
         wall_all = time.perf_counter() - t0
         torch.cuda.synchronize(dev)
         blocks = [max(e0.elapsed_time(e1) for e0, e1 in zip(marks[i], marks[i + 1])) * 1e-3 for i in range(repeats)]
+        del marks
     blocks = max_over_ranks(blocks)                              # per block: the slowest rank
     elapsed = float(np.median(blocks))
     value = n_total * a.steps / elapsed
+
+    # ---- the HOST side of a step: how long this rank's CPU thread needs to ENQUEUE one timestep (Python + ctypes + the
+    # hipLaunchKernel calls inside fiveeq_run_*), measured on a drained device with a short burst so that the HIP queue never
+    # fills (a full queue blocks the caller: that would clock the device, not the host).  Every sample starts behind a
+    # barrier, so with N ranks all N host threads enqueue AT THE SAME TIME — the contention an 8-GPU node's host side sees.
+    # host_share = enqueue time / step time: the fraction of a step the host thread is busy; < 1 means the device, not the
+    # host, paces the run (north_star's >= 7x at 8 GPUs needs this to stay well below 1 with 8 ranks enqueuing at once).
+    k_burst = max(1, min(a.steps, 40))
+    enq = []
+    for _ in range(15):
+        if a.mode == "graph":
+            prepare_graphs(t_idx % n_scen, k_burst)
+        sync_all()
+        t0 = time.perf_counter()
+        t_idx = run_steps(eng, t_idx, k_burst, a.mode, k_steps, join=False)
+        enq.append((time.perf_counter() - t0) / k_burst)
+        eng.join()
+    torch.cuda.synchronize(dev)
+    enq_med, enq_min = max_over_ranks([float(np.median(enq)), float(np.min(enq))])
     timing = {"timed_repeats": repeats, "block_ms_min_median_max": [min(blocks) * 1e3, elapsed * 1e3, max(blocks) * 1e3],
+              "device_s_clocked": float(np.sum(blocks)),
               "first_block_ms_per_step": first_max / a.steps * 1e3,
               "first_block_is": "ONE K-step block on the wall clock (barrier, device sync, clock, K steps, drained stream, "
                                 "clock; MAX over ranks): the contract's literal sample",
               "wall_ms_per_step_over_all_repeats": None if wall_all is None else
               max_over_ranks([wall_all])[0] / (a.steps * repeats) * 1e3,
-              "clocked": ("one K-step block on the wall clock (it is longer than --min-timed-ms)" if repeats == 1 else
+              "host_enqueue_us_per_step": enq_med * 1e6, "host_enqueue_us_per_step_min": enq_min * 1e6,
+              "host_share": enq_med / (elapsed / a.steps),
+              "host_enqueue_is": (f"median (and min) over 15 bursts of {k_burst} steps of the wall time this rank's thread spends "
+                                  "inside engine.run -> fiveeq_run_* (enqueue only, drained device, queue never full), every "
+                                  f"burst behind a barrier so that all {world} rank(s) enqueue at once; MAX over ranks; "
+                                  "host_share = that / ms_per_step"),
+              "clocked": ("one K-step block on the wall clock (it is longer than --timed-s)" if repeats == 1 else
                           f"{repeats} K-step blocks enqueued back to back after one barrier + device sync; block = HIP event "
                           "to HIP event on the launch stream (the slowest of the launch streams when a timestep is several "
                           "concurrent launches); MAX over ranks per block, then the median block")}
-    if repeats > 1 and eng.T is not None:
-        # the repeated blocks cycled through the scenario and overwrote stored rows with later passes: re-run the
-        # W + K steps of the first block from the initial state (untimed) so that the summary below is taken on the rows
-        # of ONE uninterrupted run, the same rows whatever the number of repeats
+    # ---- the rows the end-of-run exchange will summarise: taken NOW, from ONE uninterrupted run (the repeated blocks
+    # cycled through the scenario and overwrote stored rows with later passes; the roofline batches below overwrite more) ---
+    rows, years = None, []
+    if eng.T is not None:
         eng.reset_state()
         run_steps(eng, 0, min(a.warmup + a.steps, n_scen), a.mode, k_steps)
         torch.cuda.synchronize(dev)
-
-    # ---- end-of-run exchange (the only collective): summary statistics of T over all members.  Done NOW, on the
-    # rows the timed pass wrote, before the roofline batches below re-run (and overwrite) scenario steps. ----------
-    summary, summary_error, summary_ms, summary_stats, years = None, None, None, {}, []
-    if eng.T is not None:
-        done = min(a.warmup + a.steps, n_scen)                  # scenario steps the timed run has written
-        years = [t for t in (249, 499, 749) if t < done] or [done - 1]
-        try:
-            rows = eng.T[years]
-            gather_summary(rows, percentiles=(5.0, 50.0, 95.0))        # warm: first-call library/JIT set-up of the ops
-            sync_all()
-            ts = time.perf_counter()
-            summary = gather_summary(rows, percentiles=(5.0, 50.0, 95.0), stats=summary_stats)
-            torch.cuda.synchronize(dev)
-            summary_ms = (time.perf_counter() - ts) * 1e3
-        except Exception as exc:  # noqa: BLE001 - outside the timed region: report it, do not lose the line
-            summary = None
-            summary_error = f"{type(exc).__name__}: {exc}"
+        done_steps = min(a.warmup + a.steps, n_scen)            # scenario steps of that run
+        years = [t for t in (249, 499, 749) if t < done_steps] or [done_steps - 1]
+        rows = eng.T[years]                                     # advanced indexing: a copy
 
     # ---- roofline: per-launch duration of the timed mode's kernel, HIP events on the launch stream ----
     # The engine launches on torch's current stream, so torch.cuda.Event (hipEvent) brackets the launches.  Each
@@ -546,7 +661,7 @@ def main():
             e1.record()
             e1.synchronize()
             samples.append(e0.elapsed_time(e1) * 1e-3 / n_scen)
-        samples = np.array(samples[1:])                         # the first pass re-warms after the summary exchange
+        samples = np.array(samples[1:])                         # the first pass re-warms
         reps = -(-n_scen // span)
         k_avg = float(samples.mean())                           # seconds per model step inside the kernel
         achieved = A * n_local / k_avg / 1e9
@@ -656,27 +771,78 @@ def main():
                    "trajectory_stored": eng.C is not None, "parallelism": f"member-shard x{world}",
                    "chunk_members": eng.chunk_members,
                    "collective_backend": "rccl" if backend == "nccl" else backend,
+                   "control_plane": None if dist is None else "gloo over 127.0.0.1 (barriers, MAX of the clocked times)",
                    "emissions_sha256": emissions.emissions_sha256(E)[:16], "lhs_seed": params.LHS_SEED,
                    "lhs_design": "shard-computable (keyed Feistel bijection), drawn on the device",
                    "setup_s_rank0": setup_s},
         "roofline": roofline,
     }
-    if summary is not None and rank == 0:
-        out["summary"] = {"years": years, "gather_ms": summary_ms, "gather_ms_is": "second (warm) call",
-                          "bytes_to_root": summary_stats.get("bytes_to_root"),
-                          "allreduce_bytes": summary_stats.get("allreduce_bytes"),
-                          "T_mean": [float(x) for x in summary["mean"]],
-                          "T_p05_p50_p95": [[float(v) for v in row] for row in summary["percentiles"]]}
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+
+    # ---- end-of-run exchange (the only collective that moves ensemble data; RCCL): summary statistics of T over ALL
+    # members, on the rows captured above.  LAST, with the line already complete: a watchdog thread fires if the exchange has
+    # not returned after --summary-watchdog-s — rank 0 then prints the line with summary.error and the process exits non-zero
+    # (a fresh exit, nothing is re-executed).  Ranks other than 0 give rank 0 five more seconds before they leave, so that the
+    # launcher's tear-down cannot reach rank 0 before its line is out.
+    import threading
+    printed, emitted = threading.Lock(), []
+
+    def emit(summary_obj):
+        """Rank 0 prints THE line, once, whoever gets here first (the main thread or the watchdog)."""
+        with printed:
+            if rank == 0 and not emitted:
+                emitted.append(True)
+                if summary_obj is not None:
+                    out["summary"] = summary_obj
+                print(json.dumps(out), flush=True)
+
+    def on_timeout():
+        if rank != 0:
+            time.sleep(5.0)
+        emit({"error": f"timeout: the summary exchange had not returned after {a.summary_watchdog_s:.0f} s"})
+        print(f"rank {rank}: summary exchange timed out", file=sys.stderr, flush=True)
+        os._exit(4)
+
+    summary_error = None
+    if rows is not None:
+        watchdog = None
+        if dist is not None:
+            watchdog = threading.Timer(a.summary_watchdog_s, on_timeout)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            if os.environ.get("FIVEEQ_BENCH_HANG_SUMMARY") == str(rank):     # test hook: this rank never enters the exchange
+                time.sleep(10 * a.summary_watchdog_s + 60)
+            summary_stats = {}
+            gather_summary(rows, percentiles=(5.0, 50.0, 95.0), group=data_group)       # warm: communicator + library set-up
+            sync_all()
+            ts = time.perf_counter()
+            summ = gather_summary(rows, percentiles=(5.0, 50.0, 95.0), group=data_group, stats=summary_stats)
+            torch.cuda.synchronize(dev)
+            summary_ms = (time.perf_counter() - ts) * 1e3
+            if watchdog is not None:
+                watchdog.cancel()
+            if rank == 0:
+                emit({"years": years, "gather_ms": summary_ms, "gather_ms_is": "second (warm) call",
+                      "bytes_to_root": summary_stats.get("bytes_to_root"),
+                      "allreduce_bytes": summary_stats.get("allreduce_bytes"),
+                      "T_mean": [float(x) for x in summ["mean"]],
+                      "T_p05_p50_p95": [[float(v) for v in row] for row in summ["percentiles"]]})
+        except Exception as exc:  # noqa: BLE001 - the measurement is complete: report the failure in the line, do not lose it
+            summary_error = f"{type(exc).__name__}: {exc}"
+            if watchdog is not None:
+                watchdog.cancel()
+    else:
+        emit(None)
     if summary_error is not None:
-        out["summary"] = {"error": summary_error}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(kind, G, a.cpu_sample_members, n_scen, numpy_legs=a.numpy_baseline)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if summary_error is not None:
-        # a rank that failed inside the exchange must not walk into another collective: the peers may be stuck in
-        # the one it left.  Exit non-zero; the launcher tears the job down.
+        # A rank that failed inside the exchange must not walk into another collective: the peers may be stuck in the one
+        # it left.  Rank 0 prints its line with the error and exits; any other rank first gives rank 0 the time to reach
+        # its own error or its watchdog (the launcher tears the job down as soon as one rank has exited non-zero).
         print(f"rank {rank}: summary exchange failed: {summary_error}", file=sys.stderr, flush=True)
+        if rank != 0:
+            time.sleep(a.summary_watchdog_s + 5.0 if world > 1 else 0.0)
+        emit({"error": summary_error})
         os._exit(3)
     if dist is not None:
         dist.barrier()

@@ -10,8 +10,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+def _bench(*args, timed_s="0.05"):
+    """One plain `python bench.py ...` call.  --timed-s: these tests check the line, not the figure, so they clock 50 ms of
+    device time instead of the default 6.5 s (the driver-call test below keeps the default)."""
+    extra = [] if timed_s is None or "--timed-s" in args else ["--timed-s", timed_s]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, *extra], capture_output=True, text=True,
+                         timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -40,6 +44,9 @@ def test_default_mode_line_has_the_contract_keys():
     assert c["value"] == max(c["numpy_nproc"]["value"], c["c_port_openmp"]["value"])          # the stronger whole-box figure
     assert r["traffic_source"] is None or "traffic.json" in r["traffic_source"]
     assert d["timed_repeats"] == 1 or d["timing"]["wall_ms_per_step_over_all_repeats"] >= d["ms_per_step"] * 0.98
+    t = d["timing"]
+    assert t["device_s_clocked"] >= 0.05 and 0.0 < t["host_enqueue_us_per_step_min"] <= t["host_enqueue_us_per_step"]
+    assert abs(t["host_share"] - t["host_enqueue_us_per_step"] * 1e-3 / d["ms_per_step"]) < 1e-9 and t["host_share"] < 1.0
     s = d["summary"]
     assert len(s["T_mean"]) == len(s["years"]) and s["bytes_to_root"] == 0 and s["gather_ms"] > 0
 
@@ -58,7 +65,8 @@ def test_fused_family_lines_price_their_own_kernel():
 
 # ---- the N > 1 path: exactly what the driver launches on a multi-GPU node, rehearsed on the one GPU of the test box ----
 _SMALL = ("--steps", "20", "--warmup", "5", "--members", "200000", "--no-cpu-baseline", "--no-hbm-resident",
-          "--kernel-batches", "1")
+          "--kernel-batches", "1", "--timed-s", "0.05")
+_RANK_ENV = dict(FIVEEQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
 
 
 def _torchrun(n, *args, env=None, timeout=900):
@@ -70,9 +78,26 @@ def _torchrun(n, *args, env=None, timeout=900):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), *args]
-    full_env = dict(os.environ, FIVEEQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    full_env = dict(os.environ, **_RANK_ENV)
     full_env.update(env or {})
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=full_env)
+
+
+def _plain(n, *args, env=None, timeout=900):
+    """`python3 bench.py --gpus n ...` with NO launcher around it — the form the driver uses for --gpus 1.  For n > 1 bench.py
+    starts the ranks itself (a child torch.distributed.run, before it touches any GPU)."""
+    full_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    full_env.update(_RANK_ENV)
+    full_env.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *args], capture_output=True,
+                          text=True, timeout=timeout, env=full_env)
+
+
+def _summaries_agree(a_, b_, rel=1e-12):
+    flat = lambda v: [y for x in v for y in (x if isinstance(x, list) else [x])]     # noqa: E731
+    for key in ("T_mean", "T_p05_p50_p95"):
+        got, want = flat(a_[key]), flat(b_[key])
+        assert len(got) == len(want) and all(abs(g - w) <= rel * abs(w) for g, w in zip(got, want)), (key, a_[key], b_[key])
 
 
 def _one_line(out):
@@ -90,7 +115,8 @@ def test_multi_rank_launch_prints_one_line_and_the_world_size_invariant_summary(
         assert key in d, key
     assert d["n_gpus"] == n and d["steps"] == 20 and d["warmup"] == 5 and "cpu_baseline" not in d
     assert d["config"]["members_total"] == n * 200000 and d["config"]["collective_backend"] == "gloo"
-    assert d["timed_repeats"] >= 3 and d["timed_repeats"] % 2 == 1          # a 20-step block is well under 20 ms
+    assert d["timed_repeats"] >= 3 and d["timed_repeats"] % 2 == 1          # a 20-step block is well under 50 ms
+    assert d["config"]["control_plane"].startswith("gloo") and 0.0 < d["timing"]["host_share"]
     assert abs(d["value"] - n * 200000 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     lo_ms, med_ms, hi_ms = d["timing"]["block_ms_min_median_max"]
     assert lo_ms <= med_ms <= hi_ms and abs(med_ms - d["ms_per_step"] * 20) < 1e-9 * med_ms
@@ -101,18 +127,65 @@ def test_multi_rank_launch_prints_one_line_and_the_world_size_invariant_summary(
     one = _bench("--steps", "20", "--warmup", "5", "--members", str(n * 200000), "--no-cpu-baseline", "--no-hbm-resident",
                  "--kernel-batches", "1")
     assert one["n_gpus"] == 1 and one["summary"]["years"] == [24]
-    for key in ("T_mean", "T_p05_p50_p95"):
-        a_, b_ = (json.dumps(x[key]) for x in (d["summary"], one["summary"]))
-        got, want = json.loads(a_), json.loads(b_)
-        flat = lambda v: [y for x in v for y in (x if isinstance(x, list) else [x])]     # noqa: E731
-        for g, w in zip(flat(got), flat(want)):
-            assert abs(g - w) <= 1e-12 * abs(w), (key, got, want)
+    _summaries_agree(d["summary"], one["summary"])
+    # ... and the PLAIN form, `python3 bench.py --gpus n` with no launcher (how the driver calls --gpus 1): bench.py starts
+    # the ranks itself and the one line that comes back carries the same summary
+    pl = _one_line(_plain(n, *_SMALL))
+    assert pl["n_gpus"] == n and pl["config"]["members_total"] == n * 200000 and pl["config"]["parallelism"] == f"member-shard x{n}"
+    _summaries_agree(pl["summary"], d["summary"])
 
 
-def test_a_dead_rank_fails_the_launch():
-    out = _torchrun(2, *_SMALL, env={"FIVEEQ_BENCH_FAIL_RANK": "1"}, timeout=600)
+def test_one_rank_through_the_launcher_is_the_plain_call():
+    d = _one_line(_torchrun(1, *_SMALL))
+    one = _bench(*_SMALL)
+    assert d["n_gpus"] == one["n_gpus"] == 1 and d["config"]["control_plane"] is None
+    _summaries_agree(d["summary"], one["summary"], rel=0.0)
+
+
+@pytest.mark.parametrize("launch", ["launcher", "plain"])
+def test_a_dead_rank_fails_the_launch(launch):
+    run = _torchrun if launch == "launcher" else _plain
+    out = run(2, *_SMALL, env={"FIVEEQ_BENCH_FAIL_RANK": "1"}, timeout=600)
     assert out.returncode != 0
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_a_hung_summary_exchange_cannot_lose_the_measured_line():
+    """Rank 1 never enters the end-of-run exchange (test hook), so rank 0 sits in a collective that cannot complete —
+    what a first RCCL contact across xGMI gone wrong looks like.  The watchdog prints the complete line with summary.error
+    after --summary-watchdog-s and the job exits non-zero, long before any launcher or driver limit."""
+    import time
+    t0 = time.time()
+    out = _plain(2, *_SMALL, "--summary-watchdog-s", "8", env={"FIVEEQ_BENCH_HANG_SUMMARY": "1"}, timeout=300)
+    assert out.returncode != 0 and time.time() - t0 < 200
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert "timeout" in d["summary"]["error"] and d["value"] > 0 and d["n_gpus"] == 2 and d["roofline"]["frac"] > 0
+
+
+def test_four_ranks_enqueue_at_once_and_the_host_keeps_up():
+    """The host side of north_star's >= 7x at 8 GPUs: every rank is one Python thread issuing 2 launches per 35 us (3.5 us of
+    host time per hipLaunchKernel, profiles/r04/host_enqueue_profile.txt).  Four ranks of the driver's own workload — 1M
+    members each; with the launcher's agent and this test process that is the six processes the GPU pool allows on one card
+    (tools/host_share_rehearsal.sh goes to five outside pytest) — enqueue their bursts
+    behind a common barrier; the slowest rank's enqueue time per step must stay under half a step of ONE un-shared GPU (the
+    ranks share the card here, so the line's own step time is ~4x longer and its `host_share` would flatter the ratio)."""
+    args = ("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-hbm-resident", "--kernel-batches", "1", "--timed-s", "0.2")
+    out = _plain(4, *args)
+    d = _one_line(out)
+    assert [ln for ln in out.stdout.splitlines() if ln.strip()] == [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    solo = _bench(*args)
+    t = d["timing"]
+    assert d["n_gpus"] == 4 and d["config"]["members_per_gpu"] == 1_000_000 and t["host_enqueue_us_per_step"] > 0
+    share = t["host_enqueue_us_per_step"] * 1e-3 / solo["ms_per_step"]
+    print(f"4 ranks x 1M members: host enqueue {t['host_enqueue_us_per_step']:.2f} us/step (min "
+          f"{t['host_enqueue_us_per_step_min']:.2f}; one rank alone {solo['timing']['host_enqueue_us_per_step']:.2f}); one "
+          f"un-shared 1M-member step {solo['ms_per_step'] * 1e3:.2f} us -> host share with 4 ranks enqueuing at once {share:.3f}")
+    assert share < 0.5
+    one = _bench("--steps", "20", "--warmup", "5", "--members", "4000000", "--no-cpu-baseline", "--no-hbm-resident",
+                 "--kernel-batches", "1")
+    _summaries_agree(d["summary"], one["summary"])
 
 
 def test_one_rank_job_runs_every_collective_over_rccl():
@@ -137,8 +210,10 @@ def test_one_rank_job_runs_every_collective_over_rccl():
 def test_a_twenty_step_call_reports_what_a_full_pass_reports():
     """The driver's call is --steps 20 --warmup 5: the median of the repeated 20-step blocks must be the throughput of
     a whole 740-step pass (within box noise; the review's mark is 2 %, the assertion allows 5 %)."""
-    short = _bench("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-hbm-resident", "--kernel-batches", "1")
-    full = _bench("--steps", "740", "--warmup", "10", "--no-cpu-baseline", "--no-hbm-resident", "--kernel-batches", "1")
-    assert short["timed_repeats"] > 1 and full["timed_repeats"] == 1
+    short = _bench("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-hbm-resident", "--kernel-batches", "1",
+                   timed_s=None)                                # the driver's call: the default 6.5 s of clocked device time
+    full = _bench("--steps", "740", "--warmup", "10", "--no-cpu-baseline", "--no-hbm-resident", "--kernel-batches", "1",
+                  "--timed-s", "0")                             # ONE 740-step block on the wall clock
+    assert short["timed_repeats"] > 1000 and short["timing"]["device_s_clocked"] > 6.0 and full["timed_repeats"] == 1
     print(f"20-step median {short['value']:.4g} vs 740-step {full['value']:.4g}: ratio {short['value'] / full['value']:.4f}")
     assert abs(short["value"] / full["value"] - 1.0) < 0.05
