@@ -491,12 +491,6 @@ def main():
         # device's own clock, so a block holds its K steps and nothing else — no idle-stream launch latency, no host
         # wake-up — exactly what K steps cost inside a long run.  The wall clock around all R blocks is kept beside it as
         # the cross-check.  (The host runs ahead of the device until the HIP queue is full and is then paced by it.)
-        repeats = int(min(max(a.max_repeats, 1), -(-a.timed_s // max(first_max, 1e-6)))) | 1     # odd
-        if a.mode == "graph":
-            prepare_graphs(t_idx % n_scen, a.steps * min(repeats, -(-n_scen // a.steps) + 1))
-        torch.cuda.synchronize(dev)
-        barrier()
-        torch.cuda.synchronize(dev)
         # The per-step mode may run each timestep as several kernels on their own streams (engine.per_step_streams): a mark
         # is then one event PER STREAM, the blocks are not joined in between (a join is two cross-stream hops, ~20 us, that a
         # continuous run does not have), and a block lasts as long as its slowest stream takes from mark to mark.
@@ -508,20 +502,35 @@ def main():
                 ev.record(lane)
             return evs
 
-        t0 = time.perf_counter()
-        marks = [mark()]
-        for i in range(repeats):
-            t_idx = run_steps(eng, t_idx, a.steps, a.mode, k_steps, join=False)
-            marks.append(mark())
-        eng.join()
-        done = torch.cuda.Event()
-        done.record()
-        while not done.query():
-            pass
-        wall_all = time.perf_counter() - t0
-        torch.cuda.synchronize(dev)
-        blocks = [max(e0.elapsed_time(e1) for e0, e1 in zip(marks[i], marks[i + 1])) * 1e-3 for i in range(repeats)]
-        del marks
+        def clock_blocks(n_blocks, t_from):
+            if a.mode == "graph":
+                prepare_graphs(t_from % n_scen, a.steps * min(n_blocks, -(-n_scen // a.steps) + 1))
+            torch.cuda.synchronize(dev)
+            barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            marks = [mark()]
+            for _ in range(n_blocks):
+                t_from = run_steps(eng, t_from, a.steps, a.mode, k_steps, join=False)
+                marks.append(mark())
+            eng.join()
+            done = torch.cuda.Event()
+            done.record()
+            while not done.query():
+                pass
+            wall = time.perf_counter() - t0
+            torch.cuda.synchronize(dev)
+            out = [max(e0.elapsed_time(e1) for e0, e1 in zip(marks[i], marks[i + 1])) * 1e-3 for i in range(n_blocks)]
+            return out, wall, t_from
+
+        # how long IS a block inside a run?  The wall-clocked first block carries the idle-stream launch latency (10 % at 20
+        # steps); a short event-timed burst sizes the main loop so that it clocks --timed-s of device time, not 10 % less
+        est = first_max
+        if 12 * first_max < a.timed_s:
+            probe, _, t_idx = clock_blocks(11, t_idx)
+            est = float(np.median(max_over_ranks(probe)))
+        repeats = int(min(max(a.max_repeats, 1), -(-a.timed_s // max(est, 1e-6)))) | 1     # odd
+        blocks, wall_all, t_idx = clock_blocks(repeats, t_idx)
     blocks = max_over_ranks(blocks)                              # per block: the slowest rank
     elapsed = float(np.median(blocks))
     value = n_total * a.steps / elapsed

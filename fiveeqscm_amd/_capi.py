@@ -110,6 +110,15 @@ SIGNATURES = {
     "fiveeq_hist_rows_stats_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p, _p]),
     "fiveeq_hist_rows_stats_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p, _p]),
     "fiveeq_hist_rows_chunks": (ctypes.c_int64, [_i32, _i64]),
+    "fiveeq_row_moments_chunks": (ctypes.c_int64, [_i32, _i64]),
+    "fiveeq_row_moments_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, _p, _p, _p]),
+    "fiveeq_row_moments_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, _p, _p, _p]),
+    "fiveeq_hist_rows_ranged_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, _p, _i32, _p, _p]),
+    "fiveeq_hist_rows_ranged_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, _p, _i32, _p, _p]),
+    "fiveeq_select_bins_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, _p, _i32, _p, _p, _i64, _p, _p]),
+    "fiveeq_select_bins_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, _p, _i32, _p, _p, _i64, _p, _p]),
+    "fiveeq_select_pick_f64": (ctypes.c_int, [_i32, _i32, _i64, _p, _p, _i32, _p, _p, _p]),
+    "fiveeq_select_pick_f32": (ctypes.c_int, [_i32, _i32, _i64, _p, _p, _i32, _p, _p, _p]),
     "fiveeq_stream_copy_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
     "fiveeq_stream_copy_wide_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
     "fiveeq_math_probe_f64": (ctypes.c_int, [_i32, _i64, _p, _p, _p]),

@@ -823,21 +823,27 @@ int64_t hist_chunk(int32_t n_rows, int64_t n) {
 
 template <typename T>
 int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, double hi, int32_t n_bins,
-              uint64_t* hist, double* moments, void* stream) {
+              uint64_t* hist, double* moments, void* stream, const double* ranges = nullptr) {
     if (n_rows < 0) return fail(FIVEEQ_E_INVALID, "n_rows=%d must be >= 0", n_rows);
     if (n < 1 || ld < n) return fail(FIVEEQ_E_INVALID, "n_members=%lld, ld=%lld invalid", (long long)n, (long long)ld);
     if (n_bins < 1 || n_bins > fiveeq::HIST_MAX_BINS)
         return fail(FIVEEQ_E_INVALID, "n_bins=%d outside 1..%d", n_bins, fiveeq::HIST_MAX_BINS);
-    if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) return fail(FIVEEQ_E_INVALID, "need finite lo < hi");
+    if (!ranges && (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi))) return fail(FIVEEQ_E_INVALID, "need finite lo < hi");
     if (n_rows == 0) return FIVEEQ_OK;
     if (!rows || !hist) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
     if (n_rows > 65535) return fail(FIVEEQ_E_INVALID, "n_rows=%d exceeds the 65535 rows of one launch", n_rows);
     const int64_t chunk = hist_chunk(n_rows, n);
     const int64_t chunks = (n + chunk - 1) / chunk;
     if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
-    hipLaunchKernelGGL(fiveeq::hist_rows_kernel<T>, dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
-                       (hipStream_t)stream, n, ld, chunk, rows, lo, (double)n_bins / (hi - lo), n_bins,
-                       reinterpret_cast<unsigned long long*>(hist), moments);
+    const double inv_w = ranges ? 0.0 : (double)n_bins / (hi - lo);
+    if (moments)
+        hipLaunchKernelGGL((fiveeq::hist_rows_kernel<T, true>), dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
+                           (hipStream_t)stream, n, ld, chunk, rows, lo, inv_w, n_bins,
+                           reinterpret_cast<unsigned long long*>(hist), moments, ranges);
+    else
+        hipLaunchKernelGGL((fiveeq::hist_rows_kernel<T, false>), dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
+                           (hipStream_t)stream, n, ld, chunk, rows, lo, inv_w, n_bins,
+                           reinterpret_cast<unsigned long long*>(hist), moments, ranges);
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;
 }
@@ -900,6 +906,110 @@ int fiveeq_hist_bins(int32_t n_rows, int64_t n_members, int64_t ld, const uint16
 int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, double lo, double hi,
                          int32_t n_bins, uint64_t* hist, void* stream) {
     return hist_rows<float>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, nullptr, stream);
+}
+// ---- end-of-run summary passes (kernels 6a-6c) ----------------------------------------------------------------
+}  // extern "C"
+namespace {
+// members per workgroup of a summary pass: the histogram pass's chunking, rounded to whole 16-byte-per-lane loads
+int64_t summary_chunk(int32_t n_rows, int64_t n) {
+    const int64_t unit = 4 * FIVEEQ_BLOCK;                  // 4 floats / 2 doubles per lane: a multiple of both
+    return (hist_chunk(n_rows, n) + unit - 1) / unit * unit;
+}
+int summary_check(int32_t n_rows, int64_t n, int64_t ld, const void* rows) {
+    if (n_rows < 0) return fail(FIVEEQ_E_INVALID, "n_rows=%d must be >= 0", n_rows);
+    if (n_rows > 65535) return fail(FIVEEQ_E_INVALID, "n_rows=%d exceeds the 65535 rows of one launch", n_rows);
+    if (n < 1 || ld < n) return fail(FIVEEQ_E_INVALID, "n_members=%lld, ld=%lld invalid", (long long)n, (long long)ld);
+    if (n_rows > 0 && !rows) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    return FIVEEQ_OK;
+}
+template <typename T>
+int row_moments(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double* partial, double* moments, void* stream) {
+    if (int rc = summary_check(n_rows, n, ld, rows)) return rc;
+    if (n_rows == 0) return FIVEEQ_OK;
+    if (!partial || !moments) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    const int64_t chunk = summary_chunk(n_rows, n);
+    const int64_t chunks = (n + chunk - 1) / chunk;
+    if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
+    hipLaunchKernelGGL(fiveeq::row_moments_kernel<T>, dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
+                       (hipStream_t)stream, n, ld, chunk, rows, partial);
+    hipLaunchKernelGGL(fiveeq::row_moments_fold_kernel, dim3((unsigned)n_rows), dim3(64), 0, (hipStream_t)stream, chunks,
+                       partial, moments);
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+template <typename T>
+int select_bins(int32_t n_rows, int64_t n, int64_t ld, const T* rows, const double* ranges, int32_t n_bins,
+                const uint32_t* binmask, T* cand, int64_t cap, uint64_t* cand_n, void* stream) {
+    if (int rc = summary_check(n_rows, n, ld, rows)) return rc;
+    if (n_bins < 1 || n_bins > fiveeq::HIST_MAX_BINS)
+        return fail(FIVEEQ_E_INVALID, "n_bins=%d outside 1..%d", n_bins, fiveeq::HIST_MAX_BINS);
+    if (cap < 0) return fail(FIVEEQ_E_INVALID, "cap=%lld must be >= 0", (long long)cap);
+    if (n_rows == 0) return FIVEEQ_OK;
+    if (!ranges || !binmask || !cand_n || (cap > 0 && !cand)) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    const int64_t chunk = summary_chunk(n_rows, n);
+    const int64_t chunks = (n + chunk - 1) / chunk;
+    if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
+    hipLaunchKernelGGL(fiveeq::select_bins_kernel<T>, dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
+                       (hipStream_t)stream, n, ld, chunk, rows, ranges, n_bins, binmask, cand, cap,
+                       reinterpret_cast<unsigned long long*>(cand_n));
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+template <typename T>
+int select_pick(int32_t n_rows, int32_t n_seg, int64_t width, const T* pool, const uint64_t* seg_n, int32_t n_targets,
+                const int64_t* ranks, double* picked, void* stream) {
+    if (n_rows < 0) return fail(FIVEEQ_E_INVALID, "n_rows=%d invalid", n_rows);
+    if (n_seg < 1) return fail(FIVEEQ_E_INVALID, "n_seg=%d must be >= 1", n_seg);
+    if (width < 0) return fail(FIVEEQ_E_INVALID, "width=%lld must be >= 0", (long long)width);
+    if (n_targets < 1 || n_targets > 65535) return fail(FIVEEQ_E_INVALID, "n_targets=%d outside 1..65535", n_targets);
+    if (n_rows == 0) return FIVEEQ_OK;
+    if ((width > 0 && !pool) || !seg_n || !ranks || !picked) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    hipLaunchKernelGGL(fiveeq::select_pick_kernel<T>, dim3((unsigned)n_rows, (unsigned)n_targets), dim3(fiveeq::PICK_BLOCK), 0,
+                       (hipStream_t)stream, n_seg, width, pool, reinterpret_cast<const unsigned long long*>(seg_n), n_targets,
+                       reinterpret_cast<const long long*>(ranks), picked);
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+}  // namespace
+extern "C" {
+int fiveeq_select_pick_f64(int32_t n_rows, int32_t n_seg, int64_t width, const double* pool, const uint64_t* seg_n,
+                           int32_t n_targets, const int64_t* ranks, double* picked, void* stream) {
+    return select_pick<double>(n_rows, n_seg, width, pool, seg_n, n_targets, ranks, picked, stream);
+}
+int fiveeq_select_pick_f32(int32_t n_rows, int32_t n_seg, int64_t width, const float* pool, const uint64_t* seg_n,
+                           int32_t n_targets, const int64_t* ranks, double* picked, void* stream) {
+    return select_pick<float>(n_rows, n_seg, width, pool, seg_n, n_targets, ranks, picked, stream);
+}
+int64_t fiveeq_row_moments_chunks(int32_t n_rows, int64_t n_members) {
+    if (n_rows < 1 || n_members < 1) return 0;
+    const int64_t chunk = summary_chunk(n_rows, n_members);
+    return (n_members + chunk - 1) / chunk;
+}
+int fiveeq_row_moments_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, double* partial,
+                           double* moments, void* stream) {
+    return row_moments<double>(n_rows, n_members, ld, rows, partial, moments, stream);
+}
+int fiveeq_row_moments_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, double* partial,
+                           double* moments, void* stream) {
+    return row_moments<float>(n_rows, n_members, ld, rows, partial, moments, stream);
+}
+int fiveeq_hist_rows_ranged_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, const double* ranges,
+                                int32_t n_bins, uint64_t* hist, void* stream) {
+    if (!ranges) return fail(FIVEEQ_E_INVALID, "ranges is NULL");
+    return hist_rows<double>(n_rows, n_members, ld, rows, 0.0, 0.0, n_bins, hist, nullptr, stream, ranges);
+}
+int fiveeq_hist_rows_ranged_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, const double* ranges,
+                                int32_t n_bins, uint64_t* hist, void* stream) {
+    if (!ranges) return fail(FIVEEQ_E_INVALID, "ranges is NULL");
+    return hist_rows<float>(n_rows, n_members, ld, rows, 0.0, 0.0, n_bins, hist, nullptr, stream, ranges);
+}
+int fiveeq_select_bins_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, const double* ranges,
+                           int32_t n_bins, const uint32_t* binmask, double* cand, int64_t cap, uint64_t* cand_n, void* stream) {
+    return select_bins<double>(n_rows, n_members, ld, rows, ranges, n_bins, binmask, cand, cap, cand_n, stream);
+}
+int fiveeq_select_bins_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, const double* ranges,
+                           int32_t n_bins, const uint32_t* binmask, float* cand, int64_t cap, uint64_t* cand_n, void* stream) {
+    return select_bins<float>(n_rows, n_members, ld, rows, ranges, n_bins, binmask, cand, cap, cand_n, stream);
 }
 int fiveeq_math_probe_f64(int32_t op, int64_t n, const double* x, double* y, void* stream) {
     return math_probe<double>(op, n, x, y, stream);

@@ -729,11 +729,42 @@ __device__ __forceinline__ void wave_stats_flush(const float2v* tile /* [STAT_ST
 // bin_ring[ring_rows][ld] at row t mod ring_rows — 2 bytes per member-step where a ring of T rows takes w — for the
 // histogram pass (hist_bins_kernel) to count.  The pass no longer sees T, so the moments stay in the kernel (stats).
 constexpr unsigned short BIN_NAN = 0xFFFFu;
-__device__ __forceinline__ unsigned int fe_hist_bin(const double v, const double lo, const double inv_w, const int n_bins) {
-    const double pos = (v - lo) * inv_w;
-    const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
-    return v == v ? (unsigned int)b : (unsigned int)BIN_NAN;
-}
+// THE BIN RULE — one definition per row precision, used by every kernel that bins a value (the in-loop forms of the step /
+// fused / tiled kernels, hist_rows_kernel on stored rows, the summary's selection pass), so that "the same counts bit for
+// bit" between them is a property of this struct.  (lo, inv_w = n_bins / (hi - lo), n_bins) come in as fp64:
+//   fp64 rows:  pos = (v - lo) * inv_w                      in fp64
+//   fp32 rows:  pos = fma(v, (float)inv_w, (float)(-lo * inv_w))    in fp32 — one (packed) FMA where the fp64 form cost ~10
+//               quarter-rate instructions per lane in kernels whose ceiling is VALU issue (round 4); pos < 2^12 carries 12
+//               fractional bits, so a member changes bin against the fp64 form only within 2^-12 of a bin edge
+//   bin = pos clamped to [0, n_bins - 1] and truncated; outliers land in the edge bins; a NaN has no bin (BIN_NAN).
+// Both forms are monotone in v (rounding is), which the summary's selection relies on: members of a lower bin are <= members
+// of a higher one.
+template <typename S> struct HistRule;
+template <> struct HistRule<double> {
+    double lo, inv_w, top;
+    __device__ __forceinline__ HistRule(const double lo_, const double inv_w_, const int n_bins)
+        : lo(lo_), inv_w(inv_w_), top((double)(n_bins - 1)) {}
+    __device__ __forceinline__ unsigned int bin(const double v) const {
+        const double pos = (v - lo) * inv_w;
+        const unsigned int b = (unsigned int)(int)fmin(fmax(pos, 0.0), top);      // NaN pos -> 0 (fmax / fmin drop the NaN)
+        return v == v ? b : (unsigned int)BIN_NAN;
+    }
+};
+template <> struct HistRule<float> {
+    float scale, offset, top;
+    __device__ __forceinline__ HistRule(const double lo_, const double inv_w_, const int n_bins)
+        : scale((float)inv_w_), offset((float)(-lo_ * inv_w_)), top((float)(n_bins - 1)) {}
+    __device__ __forceinline__ unsigned int of_pos(const float pos, const float v) const {
+        const unsigned int b = (unsigned int)(int)__builtin_amdgcn_fmed3f(pos, 0.0f, top);   // v_med3_f32: the clamp in one op
+        return v == v ? b : (unsigned int)BIN_NAN;
+    }
+    __device__ __forceinline__ unsigned int bin(const float v) const { return of_pos(__builtin_fmaf(v, scale, offset), v); }
+    __device__ __forceinline__ void bin2(const float2v v, unsigned int& b0, unsigned int& b1) const {   // v_pk_fma_f32
+        const float2v pos = __builtin_elementwise_fma(v, (float2v)scale, (float2v)offset);
+        b0 = of_pos(pos.x, v.x);
+        b1 = of_pos(pos.y, v.y);
+    }
+};
 
 #ifdef FIVEEQ_STEP_WAVES
 #define FIVEEQ_STEP_ATTR __attribute__((amdgpu_waves_per_eu(FIVEEQ_STEP_WAVES, FIVEEQ_STEP_WAVES)))
@@ -806,11 +837,12 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
         }
         if constexpr (BINS) {                                            // the histogram bin of T, 2 bytes per member
             unsigned short* o = bin_ring + (int64_t)(t % ring_rows) * ld + m;
+            const HistRule<T> rule(hist_lo, hist_inv_w, n_bins);
             if constexpr (W == 1) {
-                *o = (unsigned short)fe_hist_bin((double)Tn, hist_lo, hist_inv_w, n_bins);
+                *o = (unsigned short)rule.bin(Tn);
             } else {
-                const unsigned int b0 = fe_hist_bin((double)Tn.x, hist_lo, hist_inv_w, n_bins);
-                const unsigned int b1 = fe_hist_bin((double)Tn.y, hist_lo, hist_inv_w, n_bins);
+                unsigned int b0, b1;
+                rule.bin2(Tn, b0, b1);
                 if (full) *reinterpret_cast<unsigned int*>(o) = b0 | (b1 << 16);
                 else *o = (unsigned short)b0;
             }
@@ -873,6 +905,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     V* const tile = stat_tile[threadIdx.x >> 6];
     const int n_valid = (int)min((int64_t)64 * W, n - wave * 64 * W);               // members of this wave (<= 0: none)
     int ks = 0;                                                                      // steps parked in the tile
+    const HistRule<T> rule(hist_lo, hist_inv_w, n_bins);                             // (BINS only)
 
     FIVEEQ_HOOK_FUSED_BEGIN
     V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
@@ -915,10 +948,10 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
                 if (active) {
                     unsigned short* o = bin_ring + (int64_t)((tc + k) % ring_rows) * ld + m;     // scalar row offset
                     if constexpr (W == 1) {
-                        *o = (unsigned short)fe_hist_bin((double)Tn, hist_lo, hist_inv_w, n_bins);
+                        *o = (unsigned short)rule.bin(Tn);
                     } else {
-                        const unsigned int b0 = fe_hist_bin((double)Tn.x, hist_lo, hist_inv_w, n_bins);
-                        const unsigned int b1 = fe_hist_bin((double)Tn.y, hist_lo, hist_inv_w, n_bins);
+                        unsigned int b0, b1;
+                        rule.bin2(Tn, b0, b1);
                         if (full) *reinterpret_cast<unsigned int*>(o) = b0 | (b1 << 16);    // both members: one 4-byte store
                         else *o = (unsigned short)b0;
                     }
@@ -1005,16 +1038,11 @@ __device__ __forceinline__ void wave_lds_add(unsigned int* p, const unsigned int
     }
 }
 
-// bin of one value: hist_rows_kernel's rule, bit for bit.  (Plain LDS atomics here: the aggregation round above costs ~12 VALU
-// instructions per wave-step, which this VALU-bound kernel pays in time — 69.2 -> 69.9-71.6 us/step at the config-5 shard —
-// where the memory-bound passes do not.)
-__device__ __forceinline__ void tile_hist_add(unsigned int* h_row, const double v, const double lo, const double inv_w,
-                                              const int n_bins) {
-    if (v == v) {
-        const double pos = (v - lo) * inv_w;
-        const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);
-        atomicAdd(&h_row[b >> 1], (b & 1) ? 0x10000u : 1u);
-    }
+// count one bin index into the packed 16-bit-pair LDS histogram row.  (Plain LDS atomics here: the aggregation round above
+// costs ~12 VALU instructions per wave-step, which this VALU-bound kernel pays in time — 69.2 -> 69.9-71.6 us/step at the
+// config-5 shard — where the memory-bound passes do not.)
+__device__ __forceinline__ void tile_hist_add(unsigned int* h_row, const unsigned int b) {
+    if (b != (unsigned int)BIN_NAN) atomicAdd(&h_row[b >> 1], (b & 1u) ? 0x10000u : 1u);
 }
 
 // V = lane value type: one member per lane, or two (packed fp32: a block is 2048 members and the kernel keeps the fused
@@ -1064,6 +1092,7 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
         if (threadIdx.x < NW) reinterpret_cast<T*>(&sh.km)[threadIdx.x] = src[threadIdx.x];
     }
     const KModel<T>& kmr = sh.km;
+    const HistRule<T> rule(hist_lo, hist_inv_w, n_bins);
     const int nt = t_end - t_begin;
     const int hw = (n_bins + 1) >> 1;
     const bool do_hist = hist != nullptr;
@@ -1136,10 +1165,12 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
                 }
                 if (do_hist) {
                     if constexpr (W == 1) {
-                        if (active) tile_hist_add(&h_s[k * hw], (double)Tn, hist_lo, hist_inv_w, n_bins);
+                        if (active) tile_hist_add(&h_s[k * hw], rule.bin(Tn));
                     } else {
-                        if (active) tile_hist_add(&h_s[k * hw], (double)Tn.x, hist_lo, hist_inv_w, n_bins);
-                        if (full) tile_hist_add(&h_s[k * hw], (double)Tn.y, hist_lo, hist_inv_w, n_bins);
+                        unsigned int b0, b1;
+                        rule.bin2(Tn, b0, b1);
+                        if (active) tile_hist_add(&h_s[k * hw], b0);
+                        if (full) tile_hist_add(&h_s[k * hw], b1);
                     }
                 }
                 if (wave_live) {
@@ -1255,31 +1286,39 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hfc_conc_kernel(
 constexpr int HIST_CHUNK_MIN = 16384;
 constexpr int HIST_MAX_BINS = 4096;
 
-template <typename T>
+template <typename T, bool MOM>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n, const int64_t ld, const int64_t chunk,
-                                                                 const T* __restrict__ rows, const double lo,
-                                                                 const double inv_w, const int n_bins,
+                                                                 const T* __restrict__ rows, const double lo_all,
+                                                                 const double inv_w_all, const int n_bins,
                                                                  unsigned long long* __restrict__ hist,
-                                                                 double* __restrict__ moments /* [rows][chunks][4] or nullptr */) {
+                                                                 double* __restrict__ moments /* [rows][chunks][4] or nullptr */,
+                                                                 const double* __restrict__ ranges /* [rows][2] or nullptr */) {
     __shared__ unsigned int h[HIST_MAX_BINS];
     __shared__ double red[FIVEEQ_BLOCK / 64][4];
     for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) h[b] = 0u;
     __syncthreads();
     const int64_t row = blockIdx.y;
+    // ranges != nullptr: every row has its own (lo, hi) in device memory (the summary pass: each row's global extrema);
+    // a row with hi <= lo is constant and lands in bin 0
+    const double lo = ranges ? ranges[row * 2] : lo_all;
+    const double inv_w = ranges ? (ranges[row * 2 + 1] > lo ? (double)n_bins / (ranges[row * 2 + 1] - lo) : 0.0) : inv_w_all;
     const int64_t m0 = (int64_t)blockIdx.x * chunk;
     const int64_t m1 = min(m0 + chunk, n);
     const T* x = rows + row * ld;
     const double inf = __builtin_inf();
-    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;      // this pass reads every value anyway: the moments ride along
+    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;      // MOM: this pass reads every value anyway, the moments ride along
+    const HistRule<T> rule(lo, inv_w, n_bins);
     auto count = [&](const T xv) {
-        const double v = (double)xv;
-        const double pos = (v - lo) * inv_w;
-        const int b = pos < 0.0 ? 0 : (pos >= (double)n_bins ? n_bins - 1 : (int)pos);      // a NaN lands on 0 and is not counted
-        wave_lds_add(&h[b], 1u, v == v ? (unsigned int)b : ~0u);
-        s1 += v;
-        s2 = __builtin_fma(v, v, s2);
-        mn = fmin(mn, v);
-        mx = fmax(mx, v);
+        const unsigned int b = rule.bin(xv);                                    // a NaN has no bin and is not counted
+        const bool ok = b != (unsigned int)BIN_NAN;
+        wave_lds_add(&h[ok ? b : 0u], 1u, ok ? b : ~0u);
+        if constexpr (MOM) {
+            const double v = (double)xv;
+            s1 += v;
+            s2 = __builtin_fma(v, v, s2);
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
     };
     int64_t m = m0 + threadIdx.x;
     for (; m + 3 * FIVEEQ_BLOCK < m1; m += 4 * FIVEEQ_BLOCK) {      // four independent loads in flight per lane
@@ -1290,7 +1329,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
         count(v3);
     }
     for (; m < m1; m += FIVEEQ_BLOCK) count(x[m]);
-    if (moments != nullptr) {
+    if constexpr (MOM) {
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) {
             s1 += __shfl_xor(s1, sh);
@@ -1304,7 +1343,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
         }
     }
     __syncthreads();
-    if (moments != nullptr && threadIdx.x == 0) {
+    if (MOM && threadIdx.x == 0) {
         double a = red[0][0], b = red[0][1], c = red[0][2], d = red[0][3];
 #pragma unroll
         for (int w = 1; w < FIVEEQ_BLOCK / 64; ++w) {
@@ -1360,6 +1399,336 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_bins_kernel(const int64_t n
         const unsigned int c = h[b];
         if (c) atomicAdd(&out[b], (unsigned long long)c);
     }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernels 6a-6c — the END-OF-RUN SUMMARY as HIP passes (form (i): exact percentiles by selection).
+// The host side (fiveeqscm_amd/distributed.py) needs, per output row of T over this rank's members:
+//   6a  the moments (sum, sum of squares, min, max)                      row_moments_kernel + row_moments_fold_kernel
+//   --  a 4096-bin histogram between the GLOBAL min and max              hist_rows_kernel with per-row ranges (RANGED)
+//   6c  the members of the histogram bins that hold the wanted order statistics, compacted                     select_bins_kernel
+//   6d  the order statistics, picked out of those candidates by radix selection                                select_pick_kernel
+// Each pass reads the rows once with 16-byte loads; nothing else of the ensemble's size moves.
+// ---------------------------------------------------------------------------------
+template <typename T> struct Wide;                       // 16 bytes of row per lane and load
+template <> struct Wide<double> { using V = double2; static constexpr int N = 2; };
+template <> struct Wide<float> { using V = float4; static constexpr int N = 4; };
+__device__ __forceinline__ double wide_get(const double2& v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float wide_get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// 6a.  partial[row][chunk][4] = (sum, sum of squares, min, max) of members [chunk * `chunk`, ...) of the row, fp64 sums
+// of the exactly converted elements; min / max ignore NaNs (like the kernels' own wave records), the sums propagate them.
+// Fixed summation order (lane-strided, xor-shuffle tree, wave order): the same bits on every run.
+template <typename T>
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void row_moments_kernel(const int64_t n, const int64_t ld, const int64_t chunk,
+                                                                   const T* __restrict__ rows, double* __restrict__ partial) {
+    using WV = typename Wide<T>::V;
+    constexpr int WN = Wide<T>::N;
+    __shared__ double red[FIVEEQ_BLOCK / 64][4];
+    const int64_t row = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * chunk;          // chunk is a multiple of WN * FIVEEQ_BLOCK (host)
+    const int64_t m1 = min(m0 + chunk, n);
+    const T* x = rows + row * ld;
+    const double inf = __builtin_inf();
+    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;
+    auto take = [&](const T xv) {
+        const double v = (double)xv;
+        s1 += v;
+        s2 = __builtin_fma(v, v, s2);
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+    };
+    const bool wide = ((((uintptr_t)x) | ((uintptr_t)(ld * sizeof(T)))) & 15) == 0;
+    int64_t m = m0 + (int64_t)threadIdx.x * WN;
+    if (wide) {
+        for (; m + 2 * WN * FIVEEQ_BLOCK + WN - 1 < m1; m += 3 * WN * FIVEEQ_BLOCK) {     // three independent loads in flight
+            const WV a = *reinterpret_cast<const WV*>(x + m);
+            const WV b = *reinterpret_cast<const WV*>(x + m + WN * FIVEEQ_BLOCK);
+            const WV c = *reinterpret_cast<const WV*>(x + m + 2 * WN * FIVEEQ_BLOCK);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) take(wide_get(a, j));
+#pragma unroll
+            for (int j = 0; j < WN; ++j) take(wide_get(b, j));
+#pragma unroll
+            for (int j = 0; j < WN; ++j) take(wide_get(c, j));
+        }
+        for (; m + WN - 1 < m1; m += WN * FIVEEQ_BLOCK) {
+            const WV a = *reinterpret_cast<const WV*>(x + m);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) take(wide_get(a, j));
+        }
+    }
+    for (; m < m1; m += WN * FIVEEQ_BLOCK)                      // unaligned rows, and the ragged tail of the last chunk
+        for (int j = 0; j < WN && m + j < m1; ++j) take(x[m + j]);
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        s1 += __shfl_xor(s1, sh);
+        s2 += __shfl_xor(s2, sh);
+        mn = fmin(mn, __shfl_xor(mn, sh));
+        mx = fmax(mx, __shfl_xor(mx, sh));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        double* r = red[threadIdx.x >> 6];
+        r[0] = s1, r[1] = s2, r[2] = mn, r[3] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = red[0][0], b = red[0][1], c = red[0][2], d = red[0][3];
+#pragma unroll
+        for (int w = 1; w < FIVEEQ_BLOCK / 64; ++w) {
+            a += red[w][0];
+            b += red[w][1];
+            c = fmin(c, red[w][2]);
+            d = fmax(d, red[w][3]);
+        }
+        double* o = partial + (row * gridDim.x + blockIdx.x) * 4;
+        o[0] = a, o[1] = b, o[2] = c, o[3] = d;
+    }
+}
+// moments[row][4] = the partials of a row folded in a fixed order (one wave per row)
+__global__ __launch_bounds__(64) void row_moments_fold_kernel(const int64_t chunks, const double* __restrict__ partial,
+                                                              double* __restrict__ moments) {
+    const int64_t row = blockIdx.x;
+    const double inf = __builtin_inf();
+    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;
+    for (int64_t c = threadIdx.x; c < chunks; c += 64) {
+        const double* p = partial + (row * chunks + c) * 4;
+        s1 += p[0];
+        s2 += p[1];
+        mn = fmin(mn, p[2]);
+        mx = fmax(mx, p[3]);
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        s1 += __shfl_xor(s1, sh);
+        s2 += __shfl_xor(s2, sh);
+        mn = fmin(mn, __shfl_xor(mn, sh));
+        mx = fmax(mx, __shfl_xor(mx, sh));
+    }
+    if (threadIdx.x == 0) {
+        double* o = moments + row * 4;
+        o[0] = s1, o[1] = s2, o[2] = mn, o[3] = mx;
+    }
+}
+
+// 6c.  SELECTION.  The histogram of pass 2 says, exactly, how many members lie in each bin, and the bin rule is monotone in
+// the value: the order statistic of global index i lies in the bin b with cdf[b-1] <= i < cdf[b], and is the
+// (i - cdf[b-1])-th smallest member OF THAT BIN.  So the host marks the bins that hold wanted order statistics
+// (binmask[row]: one bit per bin) and this pass, computing every member's bin with the SAME rule from the same (lo, hi),
+// appends the members of marked bins — the CANDIDATES, a few thousandths of the row — to cand[row][...] (any order).
+// Compaction: the wave's candidates take consecutive places in a workgroup LDS buffer (one LDS atomic per wave-load that has
+// any), which is appended to the row's global buffer with ONE global atomic per workgroup; a workgroup whose buffer is full
+// (a row with heavy ties) appends its further candidates directly.  cand_n[row] counts every candidate, stored or not; the
+// host sizes cap from the histogram, so it never overflows unless the caller passed a smaller one.
+constexpr int SELECT_LDS_CAND = 2048;
+template <typename T>
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void select_bins_kernel(const int64_t n, const int64_t ld, const int64_t chunk,
+                                                                   const T* __restrict__ rows, const double* __restrict__ ranges,
+                                                                   const int n_bins, const unsigned int* __restrict__ binmask,
+                                                                   T* __restrict__ cand, const int64_t cap,
+                                                                   unsigned long long* __restrict__ cand_n) {
+    using WV = typename Wide<T>::V;
+    constexpr int WN = Wide<T>::N;
+    __shared__ unsigned int mask_s[HIST_MAX_BINS / 32];
+    __shared__ T buf[SELECT_LDS_CAND];
+    __shared__ unsigned int buf_next, buf_valid;
+    __shared__ unsigned long long g_base;
+    const int64_t row = blockIdx.y;
+    const int mask_words = (n_bins + 31) >> 5;
+    if ((int)threadIdx.x < mask_words) mask_s[threadIdx.x] = binmask[row * mask_words + threadIdx.x];
+    if (threadIdx.x == 0) {
+        buf_next = 0u;
+        buf_valid = 0xffffffffu;
+    }
+    __syncthreads();
+    const double lo = ranges[row * 2], hi = ranges[row * 2 + 1];
+    const HistRule<T> rule(lo, hi > lo ? (double)n_bins / (hi - lo) : 0.0, n_bins);       // pass 2's rule for this row, bit for bit
+    const int64_t m0 = (int64_t)blockIdx.x * chunk;             // chunk is a multiple of WN * FIVEEQ_BLOCK (host)
+    const int64_t m1 = min(m0 + chunk, n);
+    const T* x = rows + row * ld;
+    T* const out = cand + row * cap;
+    const int lane = threadIdx.x & 63;
+
+    // one value per lane: place it if its bin is marked.  `have` = this lane holds a member.
+    auto take = [&](const T v, const bool have) {
+        const unsigned int b = rule.bin(v);
+        const bool is_c = have && b != (unsigned int)BIN_NAN && ((mask_s[b >> 5] >> (b & 31u)) & 1u);
+        const unsigned long long cm = __ballot(is_c);
+        if (cm != 0ull) {                                        // wave-uniform; a few per cent of the wave-loads of a smooth row
+            const unsigned int total = (unsigned int)__popcll(cm);
+            const unsigned int rank = (unsigned int)__popcll(cm & ((1ull << lane) - 1ull));
+            unsigned int pos = 0u;
+            if (lane == 0) pos = atomicAdd(&buf_next, total);
+            pos = (unsigned int)__builtin_amdgcn_readfirstlane((int)pos);
+            if (pos + total <= (unsigned int)SELECT_LDS_CAND) {
+                if (is_c) buf[pos + rank] = v;
+            } else {                                             // the workgroup's buffer is full: straight to the row's buffer
+                if (lane == 0) atomicMin(&buf_valid, pos);
+                unsigned long long gp = 0ull;
+                if (lane == 0) gp = atomicAdd(&cand_n[row], (unsigned long long)total);
+                gp = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(gp >> 32)) << 32) |
+                     (unsigned int)__builtin_amdgcn_readfirstlane((int)(gp & 0xffffffffull));
+                if (is_c && (int64_t)(gp + rank) < cap) out[gp + rank] = v;
+            }
+        }
+    };
+    const bool wide = ((((uintptr_t)x) | ((uintptr_t)(ld * sizeof(T)))) & 15) == 0;
+    // every lane of a wave runs the same number of iterations (take() is a wave-level operation): the loop bound is on the
+    // wave's first member, lanes past the end of the chunk carry have = false
+    const int64_t wave_m = m0 + (int64_t)(threadIdx.x & ~63) * WN;
+    int64_t m = m0 + (int64_t)threadIdx.x * WN;
+    constexpr int64_t STEP = (int64_t)WN * FIVEEQ_BLOCK;
+    int64_t wm = wave_m;
+    if (wide) {
+        for (; wm + STEP + 64 * WN <= m1; wm += 2 * STEP, m += 2 * STEP) {      // two independent 16-byte loads in flight
+            const WV a = *reinterpret_cast<const WV*>(x + m);
+            const WV b = *reinterpret_cast<const WV*>(x + m + STEP);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) take(wide_get(a, j), true);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) take(wide_get(b, j), true);
+        }
+    }
+    for (; wm < m1; wm += STEP, m += STEP) {
+        if (wide && wm + 64 * WN <= m1) {
+            const WV a = *reinterpret_cast<const WV*>(x + m);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) take(wide_get(a, j), true);
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const bool have = m + j < m1;
+                take(have ? x[m + j] : T(0), have);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned int kept = min(min(buf_next, buf_valid), (unsigned int)SELECT_LDS_CAND);
+    if (kept) {
+        if (threadIdx.x == 0) g_base = atomicAdd(&cand_n[row], (unsigned long long)kept);
+        __syncthreads();
+        const unsigned long long gb = g_base;
+        for (unsigned int i = threadIdx.x; i < kept; i += FIVEEQ_BLOCK)
+            if ((int64_t)(gb + i) < cap) out[gb + i] = buf[i];
+    }
+}
+
+// 6d.  PICK.  The order statistics themselves, read off the candidates WITHOUT sorting them.  ranks[row][q] is where target q
+// sits among the row's candidates taken in ascending order — integer bookkeeping on the histogram, done by the host BEFORE
+// the selection pass ran (for the order statistic of index i in bin b: the members of marked bins below b, plus i - cdf[b-1]) —
+// so selection and pick run back to back with no host round trip between them.  One 1024-thread workgroup per (row, target)
+// finds the candidate of that rank by RADIX SELECTION on the order-preserving integer image of the values: 11 bits per pass
+// from the top, a 2048-bin LDS histogram of the candidates that share the target's prefix so far (wave-aggregated: in the
+// top pass every candidate shares one bin), one wave then walks the bins to the one holding the rank.  3 (fp32) or 6 (fp64)
+// passes over a few thousand to a few hundred thousand L2-resident values.  pool[row][seg][width] holds the candidates as
+// they arrived: one segment (this rank's cand buffer), or one per rank on the root; seg_n[row][seg] valid entries each.
+// Out: picked[row][n_targets] fp64; NaN when the rank is negative or not below the row's number of candidates.
+constexpr int PICK_BLOCK = 1024;
+template <typename T> struct SortKey;
+template <> struct SortKey<float> {
+    using U = unsigned int;
+    static constexpr int BITS = 32;
+    static __device__ __forceinline__ U of(float v) {
+        const U u = __float_as_uint(v);
+        return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+    }
+    static __device__ __forceinline__ double back(U k) {
+        return (double)__uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+    }
+};
+template <> struct SortKey<double> {
+    using U = unsigned long long;
+    static constexpr int BITS = 64;
+    static __device__ __forceinline__ U of(double v) {
+        const U u = (U)__double_as_longlong(v);
+        return u ^ ((u >> 63) ? 0xffffffffffffffffull : 0x8000000000000000ull);
+    }
+    static __device__ __forceinline__ double back(U k) {
+        return __longlong_as_double((long long)(k ^ ((k >> 63) ? 0x8000000000000000ull : 0xffffffffffffffffull)));
+    }
+};
+
+constexpr int PICK_DIGIT = 11;                      // bits per radix pass: 2048 LDS bins; 3 passes for fp32, 6 for fp64
+template <typename T>
+__global__ __launch_bounds__(PICK_BLOCK) void select_pick_kernel(
+    const int n_seg, const int64_t width, const T* __restrict__ pool, const unsigned long long* __restrict__ seg_n,
+    const int n_targets, const long long* __restrict__ ranks /* [rows][n_targets] */, double* __restrict__ picked) {
+    using K = SortKey<T>;
+    using U = typename K::U;
+    __shared__ unsigned int hist[1 << PICK_DIGIT];
+    __shared__ long long rank_s;                 // remaining rank within the current prefix; < 0: no such candidate
+    __shared__ U prefix_s;
+    const int64_t row = blockIdx.x;
+    const int q = blockIdx.y;                    // ONE target per workgroup: (rows x targets) workgroups share the chip
+    const int Q = n_targets;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* const x = pool + row * n_seg * width;
+    if (threadIdx.x == 0) {
+        long long total = 0;
+        for (int g = 0; g < n_seg; ++g) total += (long long)seg_n[row * n_seg + g];
+        long long r = ranks[row * Q + q];
+        if (r < 0 || r >= total) r = -1;
+        rank_s = r;
+        prefix_s = (U)0;
+    }
+    __syncthreads();
+    if (rank_s >= 0) {                                                   // workgroup-uniform
+        for (int hi = K::BITS; hi > 0;) {
+            const int lo = hi > PICK_DIGIT ? hi - PICK_DIGIT : 0;
+            const int nb = hi - lo;
+            for (int i = threadIdx.x; i < (1 << nb); i += PICK_BLOCK) hist[i] = 0u;
+            __syncthreads();
+            const U prefix = prefix_s;
+            for (int g = 0; g < n_seg; ++g) {
+                const int64_t cnt = (int64_t)seg_n[row * n_seg + g];
+                const T* xs = x + g * width;
+                // whole waves iterate together (wave_lds_add is a wave-level operation)
+                auto tally = [&](const T v, const bool have) {
+                    const U key = K::of(v);
+                    const bool match = have && (hi >= K::BITS || (key >> hi) == prefix);
+                    const unsigned int b = (unsigned int)((key >> lo) & (U)((1u << nb) - 1u));
+                    wave_lds_add(&hist[b], 1u, match ? b : ~0u);
+                };
+                int64_t base = (int64_t)wave * 64;
+                for (; base + 3 * PICK_BLOCK + 64 <= cnt; base += 4 * PICK_BLOCK) {      // four independent loads in flight
+                    const T v0 = xs[base + lane], v1 = xs[base + PICK_BLOCK + lane], v2 = xs[base + 2 * PICK_BLOCK + lane],
+                            v3 = xs[base + 3 * PICK_BLOCK + lane];
+                    tally(v0, true);
+                    tally(v1, true);
+                    tally(v2, true);
+                    tally(v3, true);
+                }
+                for (; base < cnt; base += PICK_BLOCK) {
+                    const bool have = base + lane < cnt;
+                    tally(have ? xs[base + lane] : T(0), have);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {                                             // which bin holds the rank?  lane l owns bins [l*per, (l+1)*per)
+                const int per = (1 << nb) / 64;                          // 32 (11 bits) or 16 (10 bits)
+                const long long r = rank_s;
+                unsigned int mine = 0u;
+                for (int i = 0; i < per; ++i) mine += hist[lane * per + i];
+                unsigned int incl = mine;                                // inclusive prefix sum over the lanes
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) {
+                    const unsigned int up = __shfl_up(incl, sh);
+                    if (lane >= sh) incl += up;
+                }
+                const long long before = (long long)incl - mine;
+                if (r >= before && r < (long long)incl) {                // exactly one lane: the counts sum to more than r
+                    long long rem = r - before;
+                    int b = lane * per;
+                    while (rem >= (long long)hist[b]) rem -= hist[b++];
+                    rank_s = rem;
+                    prefix_s = (nb < K::BITS ? (prefix << nb) : (U)0) | (U)b;
+                }
+            }
+            __syncthreads();
+            hi = lo;
+        }
+    }
+    if (threadIdx.x == 0) picked[row * Q + q] = rank_s < 0 ? __builtin_nan("") : K::back(prefix_s);
 }
 
 // ---------------------------------------------------------------------------------

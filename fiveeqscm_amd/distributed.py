@@ -11,11 +11,16 @@ step: summary statistics of T (or C) at selected output times, over ALL members 
     holding the wanted order statistics are located on its cumulative counts, and only the members
     inside those bins travel to the root (a few thousand values out of 10M), where they are sorted
     and read off with NumPy's default linear interpolation.  Values keep their dtype on the wire.
+On the GPU the summary is three HIP passes over the rows (include/fiveeq.h "END-OF-RUN SUMMARY": moments, histogram
+with per-row device ranges, selection with ballot counts and LDS compaction) with the small bookkeeping between them done
+on the host in NumPy — the rows are read three times at memory speed and nothing else of their size exists; rows on the
+CPU (the gloo tests) take the same algorithm in torch ops.
 `torch.distributed` backend "nccl" is RCCL on ROCm; the same code runs on CPU tensors over gloo
 (tests/test_distributed.py).  The reference has no distributed code at all.
 """
 import os
 
+import numpy as np
 import torch
 
 
@@ -229,6 +234,10 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
     Returns [K, P] fp64 on rank `dst`, None elsewhere.  `stats`, if a dict, receives bytes_to_root / allreduce_bytes."""
     dist, rank, world, exchange = _dist(group)
     rows = rows.contiguous()
+    if rows.is_cuda and rows.dtype in (torch.float32, torch.float64) and len(percentiles) >= 1:
+        _, out = _device_summary(rows, percentiles, dst, group, stats, gmin=gmin, gmax=gmax, n_total=n_total,
+                                 want_moments=False, n_bins=n_bins)
+        return None if out is None else torch.from_numpy(out)
     K, n_local = rows.shape
     P = len(percentiles)
     dev = rows.device
@@ -337,14 +346,236 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
     return torch.where(live, out, lo_t.reshape(K, 1).expand(K, P))
 
 
-def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats=None):
+# ---------------------------------------------------------------------------------------------------------------------
+# The summary of DEVICE rows: HIP passes + host bookkeeping.
+# ---------------------------------------------------------------------------------------------------------------------
+def _lib_and_stream(rows):
+    import ctypes
+
+    from . import _capi
+    lib = _capi.load()
+    return lib, _capi, ctypes, ctypes.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)
+
+
+def _all_reduce(dist, group, x, op):
+    """all-reduce of a small device (or host) tensor over the group's backend; gloo takes device tensors through the host."""
+    if dist.get_backend(group) == "gloo" and x.is_cuda:
+        y = x.cpu()
+        dist.all_reduce(y, op=op, group=group)
+        x.copy_(y)
+    else:
+        dist.all_reduce(x, op=op, group=group)
+    return x
+
+
+def _all_gather_np(dist, group, world, arr):
+    """every rank's NumPy array `arr` (same shape and dtype everywhere) -> array [world, ...], through the group's backend."""
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if dist.get_backend(group) != "gloo":
+        t = t.cuda()
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t, group=group)
+    return torch.stack(parts).cpu().numpy()
+
+
+def device_row_sums(rows, out=None):
+    """rows [K, n] on the GPU -> device tensor [K, 4] fp64 = (sum, sum of squares, min, max) per row: ONE pass of
+    fiveeq_row_moments_* (16-byte loads, fixed summation order: the same bits every run).  min / max ignore NaNs, the sums
+    propagate them.  `out`: a [K, 4] fp64 device tensor to write into."""
+    lib, _capi, ctypes, st = _lib_and_stream(rows)
+    K, n = rows.shape
+    chunks = int(lib.fiveeq_row_moments_chunks(K, n))
+    work = torch.empty((K * chunks + (K if out is None else 0)) * 4, dtype=torch.float64, device=rows.device)
+    if out is None:
+        out = work[K * chunks * 4:].view(K, 4)
+    fn = lib.fiveeq_row_moments_f64 if rows.dtype == torch.float64 else lib.fiveeq_row_moments_f32
+    with torch.cuda.device(rows.device):
+        _capi.check(lib, fn(K, n, rows.stride(0), ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(work.data_ptr()),
+                            ctypes.c_void_p(out.data_ptr()), st))
+    return out
+
+
+def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=None, gmax=None, n_total=None,
+                    want_moments=True, n_bins=None):
+    """Moments + exact percentiles of device rows [K, n_local] over all ranks.  Returns (mom [K, 5] NumPy fp64 =
+    (count, mean, M2, min, max) merged over the ranks — None if want_moments is False —, pct [K, P] NumPy fp64 on rank `dst`
+    else None).  local_sums: this rank's [K, 4] (sum, sum^2, min, max) when the caller already has them (the engine's
+    in-kernel records); gmin / gmax / n_total: global extrema and member count when the caller already has THOSE
+    (exact_percentiles' signature) — then no moments pass runs at all.
+
+    The histogram between the global extrema holds EXACT counts and its bin rule is monotone in the value, so the order
+    statistic of global index i is the (i - cdf[b-1])-th smallest member of the bin b with cdf[b-1] <= i < cdf[b].  Hence:
+    moments pass -> histogram pass (one rank: ranges straight from the moments, on the device) -> ONE device-to-host copy
+    (moments + counts) -> the host marks the bins that hold wanted order statistics and computes each statistic's rank among
+    the members of marked bins -> ONE upload -> selection pass (members of marked bins, compacted) -> pick pass (radix
+    selection of those ranks) -> ONE copy back.  Several ranks add the exchanges where the text below says so."""
+    dist, rank, world, exchange = _dist(group)
+    lib, _capi, ctypes, st = _lib_and_stream(rows)
+    n_bins = SELECT_BINS if n_bins is None else int(n_bins)
+    K, n_local = rows.shape
+    P = len(percentiles)
+    Q = 2 * P
+    dev = rows.device
+    f64 = rows.dtype == torch.float64
+    w = rows.element_size()
+    sfx = "f64" if f64 else "f32"
+    ptr = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)      # noqa: E731
+    if P < 1:
+        raise ValueError("no percentiles asked for")
+    ld = rows.stride(0)
+    host_wire = exchange and dist.get_backend(group) == "gloo"
+
+    # one device buffer for everything that comes back after the histogram: counts [K, n_bins] int64, then sums [K, 4] fp64
+    head = torch.zeros(K * n_bins + K * 4, dtype=torch.int64, device=dev)
+    counts = head[:K * n_bins].view(K, n_bins)
+    sums_dev = head[K * n_bins:].view(torch.float64).view(K, 4)
+
+    # ---- pass 1: moments (unless the caller brought them), and with them the global extrema ---------------------------
+    mom = None
+    have_sums = gmin is None or want_moments
+    if have_sums:
+        if local_sums is not None:
+            sums_dev.copy_(local_sums.to(device=dev, dtype=torch.float64))
+        else:
+            device_row_sums(rows, out=sums_dev)
+    lo_np = hi_np = None
+    if exchange or gmin is not None:
+        if have_sums:
+            mine = np.concatenate([np.full((K, 1), float(n_local)), sums_dev.cpu().numpy()], axis=1)      # [K, 5]
+            parts = _all_gather_np(dist, group, world, mine) if exchange else mine[None]
+            cnt, s1 = parts[:, :, 0], parts[:, :, 1]
+            mean_r = s1 / cnt
+            m2_r = np.maximum(parts[:, :, 2] - cnt * mean_r * mean_r, 0.0)
+            mom = merge_moments(torch.from_numpy(np.stack([cnt, mean_r, m2_r, parts[:, :, 3], parts[:, :, 4]], axis=2))).numpy()
+        if gmin is None:
+            lo_np, hi_np, n_tot = mom[:, 3].copy(), mom[:, 4].copy(), int(round(float(mom[0, 0])))
+        else:
+            lo_np = np.asarray(gmin.detach().cpu() if isinstance(gmin, torch.Tensor) else gmin, dtype=np.float64).reshape(K).copy()
+            hi_np = np.asarray(gmax.detach().cpu() if isinstance(gmax, torch.Tensor) else gmax, dtype=np.float64).reshape(K).copy()
+            n_tot = int(n_total)
+        ranges = torch.from_numpy(np.stack([lo_np, hi_np], axis=1)).to(dev)
+    else:
+        ranges = sums_dev[:, 2:4].contiguous()          # one rank: the extrema never leave the device before the histogram
+        n_tot = n_local
+
+    # ---- pass 2: histograms between the global extrema ------------------------------------------------------------------
+    with torch.cuda.device(dev):
+        _capi.check(lib, getattr(lib, f"fiveeq_hist_rows_ranged_{sfx}")(K, n_local, ld, ptr(rows), ptr(ranges), n_bins,
+                                                                        ptr(counts), st))
+    if exchange:
+        _all_reduce(dist, group, counts, dist.ReduceOp.SUM)
+    head_np = head.cpu().numpy()                          # THE device-to-host copy of a one-rank summary's first half
+    counts_np = head_np[:K * n_bins].reshape(K, n_bins)
+    if lo_np is None:
+        sums_np = head_np[K * n_bins:].view(np.float64).reshape(K, 4)
+        cnt = np.full(K, float(n_local))
+        mean_r = sums_np[:, 0] / cnt
+        mom = np.stack([cnt, mean_r, np.maximum(sums_np[:, 1] - cnt * mean_r * mean_r, 0.0), sums_np[:, 2], sums_np[:, 3]], axis=1)
+        lo_np, hi_np = sums_np[:, 2].copy(), sums_np[:, 3].copy()
+    cdf = np.cumsum(counts_np, axis=1)
+    # a NaN member has no bin: a row whose counts do not add up to the member count holds one, and np.percentile of it is NaN
+    nan_row = cdf[:, -1] != n_tot
+    if stats is not None:
+        stats["bytes_to_root"], stats["allreduce_bytes"] = 0, (counts.numel() * 8 if exchange else 0)
+
+    # ---- host: the bins that hold the wanted order statistics, and each statistic's rank among the members of marked bins ---
+    pos = np.array([float(p) / 100.0 * (n_tot - 1) for p in percentiles])
+    i0 = np.floor(pos).astype(np.int64)
+    i1 = np.minimum(i0 + 1, n_tot - 1)
+    frac = pos - i0
+    want = np.concatenate([i0, i1])                                                     # [2P] global order-statistic indices
+    bb = np.stack([np.searchsorted(cdf[k], want, side="right") for k in range(K)]).clip(max=n_bins - 1)     # [K, 2P]
+    flat = ~(hi_np > lo_np)                              # a constant row: every member IS the answer, nothing to select
+    skip = nan_row | flat
+    bb[skip] = 0
+    rk = np.arange(K)[:, None]
+    marked = np.zeros((K, n_bins), dtype=bool)
+    marked[rk, bb] = True
+    marked[skip] = False
+    below_bin = np.concatenate([np.zeros((K, 1), dtype=np.int64), cdf[:, :-1]], axis=1)                      # members in bins < b
+    cand_below = np.concatenate([np.zeros((K, 1), dtype=np.int64), np.cumsum(counts_np * marked, axis=1)[:, :-1]], axis=1)
+    ranks = cand_below[rk, bb] + (want[None, :] - below_bin[rk, bb])                    # [K, 2P]
+    ranks[skip] = -1
+    n_cand = (counts_np * marked).sum(axis=1)                                            # candidates per row over ALL ranks
+    cap = max(1, int(min(n_local, n_cand.max())))
+    words = (n_bins + 31) // 32
+    bits = np.zeros((K, words * 32), dtype=np.uint8)
+    bits[:, :n_bins] = marked
+    binmask = np.packbits(bits.reshape(K, words, 32), axis=2, bitorder="little").view(np.uint32).reshape(K, words)
+
+    # ---- ONE upload: ranks [K, 2P] int64, then the bin masks [K, words] uint32 ------------------------------------------
+    up = torch.from_numpy(np.concatenate([ranks.astype(np.int64).reshape(-1).view(np.uint8), binmask.reshape(-1).view(np.uint8)])).to(dev)
+    o_mask = K * Q * 8
+
+    # ---- pass 3: selection; pass 4: pick.  tail = [cand_n K (uint64) | picked K*2P (fp64)] ----------------------------------
+    select = getattr(lib, f"fiveeq_select_bins_{sfx}")
+    pick = getattr(lib, f"fiveeq_select_pick_{sfx}")
+    tail = torch.zeros(K + K * Q, dtype=torch.int64, device=dev)
+    cand = torch.empty((K, cap), dtype=rows.dtype, device=dev)
+    with torch.cuda.device(dev):
+        _capi.check(lib, select(K, n_local, ld, ptr(rows), ptr(ranges), n_bins, ptr(up, o_mask), ptr(cand), cap, ptr(tail), st))
+        if not exchange:
+            _capi.check(lib, pick(K, 1, cap, ptr(cand), ptr(tail), Q, ptr(up), ptr(tail, K * 8), st))
+    tail_np = tail.cpu().numpy()                          # one rank: THE second (and last) device-to-host copy
+    cand_n = tail_np[:K]
+    tot_c = cand_n
+    if exchange:
+        # several ranks: the candidates travel to the root (a few thousand values out of the ensemble) and the root's pick
+        # pass runs over one segment per rank
+        all_n = _all_gather_np(dist, group, world, cand_n)                             # [world, K]
+        width = max(int(all_n.max()), 1)
+        send = cand[:, :min(width, cap)]
+        if send.shape[1] < width:
+            send = torch.cat([send, send.new_zeros((K, width - send.shape[1]))], dim=1)
+        send = send.contiguous()
+        if host_wire:
+            send = send.cpu()
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, recv, dst=dst, group=group)
+        if stats is not None:
+            stats["bytes_to_root"] = int(all_n.sum() - all_n[dst].sum()) * w
+        if rank != dst:
+            return mom, None
+        pool = torch.stack(recv, dim=1).to(dev).contiguous()                           # [K, world, width]
+        seg_n = torch.from_numpy(np.ascontiguousarray(all_n.T)).to(dev)                # [K, world]
+        with torch.cuda.device(dev):
+            _capi.check(lib, pick(K, world, width, ptr(pool), ptr(seg_n), Q, ptr(up), ptr(tail, K * 8), st))
+        tail_np = tail.cpu().numpy()
+        tot_c = all_n.sum(axis=0)
+    picked = tail_np[K:].view(np.float64).reshape(K, Q)
+    c0, c1 = picked[:, :P], picked[:, P:]
+    # the selection pass must have found exactly the members the histogram counted in the marked bins (same rule, same ranges)
+    if not np.array_equal(tot_c[~skip], n_cand[~skip]):
+        k = int(np.argwhere((tot_c != n_cand) & ~skip)[0, 0])
+        raise RuntimeError(f"percentile selection: row {k} has {int(tot_c[k])} candidates where the histogram counts {int(n_cand[k])}")
+    with np.errstate(invalid="ignore"):
+        good = skip[:, None] | ((c0 <= c1) & (c0 >= lo_np[:, None]) & (c1 <= hi_np[:, None]))
+        if not good.all():
+            k, j = [int(v) for v in np.argwhere(~good)[0]]
+            raise RuntimeError(f"percentile selection lost its order statistic (row {k}, p={percentiles[j]}): ranks "
+                               f"{int(ranks[k, j])},{int(ranks[k, j + P])} of {int(tot_c[k])} candidates, values {c0[k, j]}, {c1[k, j]}")
+        out = c0 + (c1 - c0) * frac[None, :]
+    out = np.where(nan_row[:, None], np.nan, np.where(flat[:, None], np.broadcast_to(lo_np[:, None], (K, P)), out))
+    return mom, out
+
+
+def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats=None, local_sums=None):
     """rows [K, n_local]: this rank's members at K output times.  Collective over `group`.
     Returns on every rank a dict with the merged moments (mean, var, min, max, count; [K] each, fp64);
     on rank `dst` it also holds 'percentiles' [K, len(percentiles)] over ALL members (None elsewhere) —
     exact (NumPy 'linear'), found by selection (see the module docstring).  `stats` (dict) receives
-    'bytes_to_root' (candidate members the root received) and 'allreduce_bytes' (the histogram)."""
+    'bytes_to_root' (candidate members the root received) and 'allreduce_bytes' (the histogram).
+    Rows on the GPU go through the HIP passes (moments, histogram, selection); `local_sums` [K, 4] = this rank's
+    (sum, sum of squares, min, max) per row spares them the moments pass when the caller already has those — the
+    engine's in-kernel records, EnsembleEngine.gather_summary."""
     dist, rank, world, exchange = _dist(group)
-    rows = _comm_tensor(dist, group, rows.contiguous())
+    rows = rows.contiguous()
+    if rows.is_cuda and rows.dtype in (torch.float32, torch.float64):
+        mom_np, pct_np = _device_summary(rows, percentiles, dst, group, stats, local_sums=local_sums)
+        mom = torch.from_numpy(mom_np)           # a few numbers per row: they stay on the host (HOST tensors for device rows)
+        return {"count": mom[:, 0].clone(), "mean": mom[:, 1].clone(), "var": mom[:, 2] / mom[:, 0], "min": mom[:, 3].clone(),
+                "max": mom[:, 4].clone(), "percentiles": None if pct_np is None else torch.from_numpy(pct_np)}
+    rows = _comm_tensor(dist, group, rows)
     mom = local_moments(rows)
     if exchange:
         parts = [torch.empty_like(mom) for _ in range(world)]
@@ -352,9 +583,7 @@ def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats
         mom = merge_moments(torch.stack(parts))
     n_total = int(round(float(mom[0, 0].item())))
     if not exchange and rows.shape[1] <= (1 << 21):
-        # nothing to exchange and a moderate row: a device sort is as fast as anything (1.7 ms for 3 x 1M fp64 values
-        # with the moments, warm).  Selection pays off when the alternative is moving every rank's rows, and on long
-        # rows even on one rank (3 x 12.5M values: 2.6 ms against 16 ms).
+        # nothing to exchange and a moderate row on the host: a sort is as fast as anything
         if stats is not None:
             stats["bytes_to_root"], stats["allreduce_bytes"] = 0, 0
         pct = percentiles_sorted(torch.sort(rows, dim=1).values.to(torch.float64), percentiles)

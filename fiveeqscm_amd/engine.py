@@ -820,6 +820,26 @@ class EnsembleEngine:
         from .distributed import moments_from_sums
         return moments_from_sums(self.stats_sums(t_begin, t_end))
 
+    def gather_summary(self, steps, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats=None):
+        """End-of-run summary of T at the stored `steps` over ALL members of all ranks (collective over `group`; see
+        distributed.gather_summary): merged moments on every rank, exact percentiles on rank `dst`.  With
+        collect_stats the moments come from the records the kernels wrote while stepping — the summary then reads the
+        rows twice (histogram, selection) instead of three times."""
+        from .distributed import gather_summary
+        if self.T is None:
+            raise RuntimeError("no stored T rows to summarise")
+        if self._ps_unjoined:
+            self.join()
+        row_of = {int(t): r for r, t in enumerate(self.out_steps)}
+        missing = [int(t) for t in steps if int(t) not in row_of]
+        if missing:
+            raise ValueError(f"steps {missing} are not stored (out_steps)")
+        rows = self.T[[row_of[int(t)] for t in steps]]
+        sums = None
+        if self.collect_stats:
+            sums = torch.cat([self.stats_sums(int(t), int(t) + 1) for t in steps])[:, 1:5].contiguous()
+        return gather_summary(rows, percentiles, dst=dst, group=group, stats=stats, local_sums=sums)
+
     def T_histogram(self, lo, hi, n_bins=4096, rows=None, out=None, stream=None):
         """Fixed-bin histograms of the stored T rows on the device: int64 tensor [n_rows, n_bins]
         (bin b counts lo + b w <= T < lo + (b+1) w; outliers land in the edge bins).  `out` lets

@@ -256,6 +256,11 @@ int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time,
 /* new — fixed-bin histograms of stored rows, for all-timestep percentiles with a tiny exchange
  * (SURVEY.md section 8e-ii): hist[row][b] += number of members with lo + b*w <= rows[row][m] < lo + (b+1)*w,
  * w = (hi - lo)/n_bins; values outside [lo, hi) are counted in the edge bins, NaNs are skipped.
+ * THE BIN RULE, shared bit for bit by every entry point that bins a value (these, the in-loop histograms of
+ * fiveeq_run_tiled_*, the bin indices of fiveeq_run_*bins_*, the summary's selection): with inv_w = n_bins/(hi - lo),
+ *   _f64:  bin = trunc(clamp((x - lo) * inv_w, 0, n_bins - 1))                        evaluated in fp64
+ *   _f32:  bin = trunc(clamp(fma(x, (float)inv_w, (float)(-lo*inv_w)), 0, n_bins - 1)) evaluated in fp32 (one FMA per
+ *          member; a member's bin differs from the fp64 formula's only within 2^-12 of a bin edge).
  *   rows dev [n_rows][ld] (e.g. T_traj), hist dev [n_rows][n_bins] uint64, ACCUMULATED INTO (zero it first;
  *   several shards / calls may add into the same histogram), 1 <= n_bins <= 4096, n_rows <= 65535. */
 int fiveeq_hist_rows_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double *rows,
@@ -271,6 +276,48 @@ int fiveeq_hist_rows_stats_f64(int32_t n_rows, int64_t n_members, int64_t ld, co
 int fiveeq_hist_rows_stats_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
                                double lo, double hi, int32_t n_bins, uint64_t *hist, double *moments, void *stream);
 int64_t fiveeq_hist_rows_chunks(int32_t n_rows, int64_t n_members);
+
+/* new — the END-OF-RUN SUMMARY as HIP passes (form (i): exact percentiles of T at selected output
+ * times over ALL members by SELECTION, so that the ensemble does not travel; host side: fiveeqscm_amd/distributed.py).
+ * All three read rows dev [n_rows][ld] once, 16 bytes per lane and load.
+ *
+ * (1) moments dev [n_rows][4] fp64 = (sum, sum of squares, min, max) of each row's n_members values — fp64 sums of the
+ *     exactly converted elements in a fixed order (same bits every run); min / max ignore NaNs, the sums propagate them.
+ *     partial dev [n_rows][K][4] fp64 is workspace, K = fiveeq_row_moments_chunks(n_rows, n_members). */
+int64_t fiveeq_row_moments_chunks(int32_t n_rows, int64_t n_members);
+int fiveeq_row_moments_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double *rows,
+                           double *partial, double *moments, void *stream);
+int fiveeq_row_moments_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
+                           double *partial, double *moments, void *stream);
+/* (2) fiveeq_hist_rows_* with a range PER ROW read from device memory — ranges dev [n_rows][2] fp64 = (lo, hi), e.g. each
+ *     row's global extrema, so that no host round trip sits between the moments and the histogram; a row with hi <= lo is
+ *     constant and is counted in bin 0. */
+int fiveeq_hist_rows_ranged_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double *rows,
+                                const double *ranges, int32_t n_bins, uint64_t *hist, void *stream);
+int fiveeq_hist_rows_ranged_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
+                                const double *ranges, int32_t n_bins, uint64_t *hist, void *stream);
+/* (3) selection.  The histogram of (2) holds exact counts and the bin rule is monotone in the value, so the order statistic
+ *     of global index i lies in the bin b with cdf[b-1] <= i < cdf[b] and is the (i - cdf[b-1])-th smallest member of it.
+ *     binmask dev [n_rows][ceil(n_bins/32)] uint32 marks, per row, the bins that hold wanted order statistics (bit b%32 of
+ *     word b/32); the pass recomputes every member's bin with the rule and the ranges of (2), bit for bit, and appends the
+ *     members of marked bins — the candidates — to cand dev [n_rows][cap] (any order within a row).  cand_n dev [n_rows]
+ *     uint64, ACCUMULATED INTO, counts the candidates FOUND; those beyond cap are counted but not stored. */
+int fiveeq_select_bins_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double *rows,
+                           const double *ranges, int32_t n_bins, const uint32_t *binmask,
+                           double *cand, int64_t cap, uint64_t *cand_n, void *stream);
+int fiveeq_select_bins_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
+                           const double *ranges, int32_t n_bins, const uint32_t *binmask,
+                           float *cand, int64_t cap, uint64_t *cand_n, void *stream);
+/* (4) pick: the order statistics, read off the candidates without sorting them.  ranks dev [n_rows][n_targets] int64: where
+ *     each target sits among the row's candidates in ascending order (host bookkeeping on the histogram: the members of
+ *     marked bins below the target's bin, plus i - cdf[b-1]); one workgroup per (row, target) finds the candidate of that
+ *     rank by radix selection.  pool dev [n_rows][n_seg][width]: the candidates as they arrived, seg_n dev [n_rows][n_seg]
+ *     valid entries per segment (one segment: cand / cand_n of (3); on the root of a multi-rank exchange: one segment per
+ *     rank).  picked dev [n_rows][n_targets] fp64; NaN where the rank is negative or not below the number of candidates. */
+int fiveeq_select_pick_f64(int32_t n_rows, int32_t n_seg, int64_t width, const double *pool, const uint64_t *seg_n,
+                           int32_t n_targets, const int64_t *ranks, double *picked, void *stream);
+int fiveeq_select_pick_f32(int32_t n_rows, int32_t n_seg, int64_t width, const float *pool, const uint64_t *seg_n,
+                           int32_t n_targets, const int64_t *ranks, double *picked, void *stream);
 
 /* STREAMED HISTOGRAMS through a ring of BIN INDICES (round 3).  fiveeq_run_fused_bins_* is
  * fiveeq_run_fused_* (same arguments, same results, C_traj / T_traj / T_stats as there) that ALSO writes, for every step t of

@@ -851,10 +851,20 @@ def test_histogram_kernel_and_percentiles(gpu, dtype):
     lo, hi, nb = -0.05, float(T.max()) * 0.9, 1024                    # hi below the maximum: exercises the edge bin
     h = eng.T_histogram(lo, hi, nb)
     torch.cuda.synchronize()
-    pos = np.floor((T - lo) * (nb / (hi - lo))).astype(np.int64).clip(0, nb - 1)
+    if dtype == "f64":
+        pos = np.floor((T - lo) * (nb / (hi - lo))).astype(np.int64).clip(0, nb - 1)
+    else:
+        # THE BIN RULE of fp32 rows (include/fiveeq.h): pos = fma(x, (float)inv_w, (float)(-lo * inv_w)) in fp32, clamped, truncated.
+        # Restated in fp64 — the product of two floats is exact there and the sum nearly always is — and rounded to fp32 once.
+        inv_w = nb / (hi - lo)
+        pos32 = (T * np.float64(np.float32(inv_w)) + np.float64(np.float32(-lo * inv_w))).astype(np.float32)
+        pos = np.trunc(np.clip(pos32, 0.0, nb - 1)).astype(np.int64)
+        edge = np.abs(pos32 - np.round(pos32)) < 2.0 ** -11           # where the fp64 formula may choose the neighbouring bin
+        pos64 = np.floor((T - lo) * inv_w).astype(np.int64).clip(0, nb - 1)
+        assert (pos != pos64).sum() <= edge.sum() and np.abs(pos - pos64).max() <= 1
     want = np.stack([np.bincount(r, minlength=nb) for r in pos])
     got = h.cpu().numpy()
-    # a value sitting exactly on a bin edge may round differently in (v-lo)*inv_w: allow moving <= 2 counts per row
+    # a value sitting exactly on a bin edge may round differently in the device's arithmetic: allow moving <= 2 counts per row
     assert np.abs(got - want).sum(1).max() <= 4 and np.array_equal(got.sum(1), np.full(n_steps, N))
     eng.T_histogram(lo, hi, nb, out=h)                                # accumulate: counts double
     torch.cuda.synchronize()

@@ -1,0 +1,158 @@
+"""The end-of-run summary as HIP passes (fiveeq_row_moments_*, fiveeq_hist_rows_ranged_*, fiveeq_select_rows_*; host side
+fiveeqscm_amd/distributed.py): moments and EXACT percentiles of device rows against NumPy, on the shapes that break
+selection schemes — ties, constant rows, heavy tails, NaNs, rows of a handful of members, unaligned rows."""
+import ctypes
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+PCT = (0.0, 5.0, 33.3, 49.999, 50.0, 50.001, 95.0, 100.0)
+
+
+def _rows(n, rng):
+    x = np.stack([
+        rng.normal(1.8, 0.6, size=n),                                # an ensemble temperature row
+        rng.uniform(size=n) ** 3,                                    # skewed towards the lower edge
+        np.full(n, 2.5),                                             # constant
+        np.round(rng.normal(size=n), 1),                             # ~80 distinct values: every bin is a heavy tie
+        rng.standard_cauchy(size=n),                                 # heavy tails: nearly all members in a few of the 4096 bins
+        np.where(rng.uniform(size=n) < 0.9, 0.25, rng.normal(size=n)),   # 90 % of the members share one value
+    ])
+    return x
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_percentile_selection_on_device_rows(dtype):
+    from fiveeqscm_amd.distributed import device_row_sums, exact_percentiles, gather_summary
+    rng = np.random.default_rng(2026)
+    np_dt, t_dt = (np.float64, torch.float64) if dtype == "f64" else (np.float32, torch.float32)
+    for n in (1, 2, 5, 63, 64, 65, 1000, 4097, 200_001, 3_000_001):
+        xs = _rows(n, rng).astype(np_dt)
+        t = torch.from_numpy(xs).cuda()
+        st = {}
+        out = gather_summary(t, PCT, stats=st)
+        x64 = xs.astype(np.float64)
+        want = np.percentile(x64, PCT, axis=1).T
+        np.testing.assert_allclose(out["percentiles"].cpu().numpy(), want, rtol=1e-14, atol=0, err_msg=f"n={n}")
+        assert st["bytes_to_root"] == 0 and st["allreduce_bytes"] == 0
+        np.testing.assert_allclose(out["mean"].cpu().numpy(), x64.mean(1), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(out["var"].cpu().numpy(), x64.var(1), rtol=1e-8, atol=1e-9 * (x64 ** 2).mean(1).max())
+        assert np.array_equal(out["min"].cpu().numpy(), x64.min(1)) and np.array_equal(out["max"].cpu().numpy(), x64.max(1))
+        assert out["count"].tolist() == [float(n)] * xs.shape[0]
+        # the same selection with the extrema handed in (exact_percentiles' signature: no moments pass)
+        sel = exact_percentiles(t, PCT, torch.from_numpy(x64.min(1)), torch.from_numpy(x64.max(1)), n)
+        np.testing.assert_allclose(sel.cpu().numpy(), want, rtol=1e-14, atol=0)
+        # the moments pass is deterministic
+        assert torch.equal(device_row_sums(t), device_row_sums(t))
+
+
+def test_rows_with_a_nan_and_rows_that_are_not_aligned():
+    from fiveeqscm_amd.distributed import device_row_sums, gather_summary
+    rng = np.random.default_rng(7)
+    n = 100_003
+    x = rng.normal(size=(3, n))
+    x[1, 77] = np.nan
+    out = gather_summary(torch.from_numpy(x).cuda(), (5.0, 50.0, 95.0))
+    pct = out["percentiles"].cpu().numpy()
+    np.testing.assert_allclose(pct[[0, 2]], np.percentile(x[[0, 2]], (5.0, 50.0, 95.0), axis=1).T, rtol=1e-14)
+    assert np.isnan(pct[1]).all() and np.isnan(out["mean"][1].item())            # like np.percentile / np.mean
+    assert out["min"][1].item() == np.nanmin(x[1]) and out["max"][1].item() == np.nanmax(x[1])     # extrema skip the NaN
+    # a view that starts one element into a wider buffer: rows neither 16-byte aligned nor contiguous (ld = n + 5)
+    for dt, np_dt in ((torch.float64, np.float64), (torch.float32, np.float32)):
+        wide = torch.from_numpy(rng.normal(size=(4, n + 5)).astype(np_dt)).cuda()
+        view = wide[:, 1:n + 1]
+        assert view.stride(0) == n + 5 and view.data_ptr() % 16 != 0
+        got = device_row_sums(view).cpu().numpy()
+        v = view.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(got[:, 0], v.sum(1), rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(got[:, 1], (v * v).sum(1), rtol=1e-12)
+        assert np.array_equal(got[:, 2], v.min(1)) and np.array_equal(got[:, 3], v.max(1))
+
+
+def test_selection_and_pick_through_the_c_abi():
+    """fiveeq_hist_rows_ranged_* / fiveeq_select_bins_* / fiveeq_select_pick_* called directly: the candidates are exactly the
+    members the histogram counted in the marked bins (same rule, same ranges), a cap too small for them still counts them
+    all, and the pick pass returns the k-th smallest candidate for every k asked — over one segment and over three."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(3)
+    n, nb = 300_007, 1000
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    for np_dt, sfx in ((np.float64, "f64"), (np.float32, "f32")):
+        x = rng.normal(size=(2, n)).astype(np_dt)
+        x[0, 5] = np.nan
+        rows = torch.from_numpy(x).cuda()
+        ranges = torch.tensor([[-1.5, 2.0], [np.nanmin(x[1]), np.nanmax(x[1])]], dtype=torch.float64, device="cuda")
+        hist = torch.zeros((2, nb), dtype=torch.int64, device="cuda")
+        _capi.check(lib, getattr(lib, f"fiveeq_hist_rows_ranged_{sfx}")(2, n, n, p(rows), p(ranges), nb, p(hist), None))
+        counts = hist.cpu().numpy()
+        assert counts.sum(1).tolist() == [n - 1, n]                                  # the NaN has no bin
+        marked = rng.uniform(size=(2, nb)) < 0.01
+        marked[:, [0, nb - 1]] = True                                                # the edge bins hold the outliers
+        words = (nb + 31) // 32
+        bits = np.zeros((2, words * 32), dtype=np.uint8)
+        bits[:, :nb] = marked
+        mask = torch.from_numpy(np.packbits(bits.reshape(2, words, 32), axis=2, bitorder="little").view(np.uint32).reshape(2, words).view(np.int32)).cuda()
+        want_n = (counts * marked).sum(1)
+        for cap in (100, int(want_n.max())):                                         # too small first: everything is still counted
+            cand = torch.full((2, cap), -777.0, dtype=rows.dtype, device="cuda")
+            cand_n = torch.zeros(2, dtype=torch.int64, device="cuda")
+            _capi.check(lib, getattr(lib, f"fiveeq_select_bins_{sfx}")(2, n, n, p(rows), p(ranges), nb, p(mask), p(cand), cap,
+                                                                       p(cand_n), None))
+            assert cand_n.cpu().tolist() == want_n.tolist()
+        got = [np.sort(cand[k, :want_n[k]].cpu().numpy()) for k in range(2)]
+        # the candidates are whole bins: contiguous runs of the sorted row
+        srt = np.sort(x[1])
+        edges = np.concatenate([[0], np.cumsum(counts[1])])
+        assert np.array_equal(got[1], np.concatenate([srt[edges[b]:edges[b + 1]] for b in np.nonzero(marked[1])[0]]))
+        # pick: ranks 0, 1, middle, last, one past the end (-> NaN), negative (-> NaN)
+        ranks = np.stack([[0, 1, want_n[k] // 2, want_n[k] - 1, want_n[k], -1] for k in range(2)]).astype(np.int64)
+        picked = torch.zeros((2, 6), dtype=torch.float64, device="cuda")
+        ranks_t = torch.from_numpy(ranks).cuda()                  # (kept alive: the calls below only see pointers)
+        _capi.check(lib, getattr(lib, f"fiveeq_select_pick_{sfx}")(2, 1, cand.shape[1], p(cand), p(cand_n), 6, p(ranks_t),
+                                                                   p(picked), None))
+        pk = picked.cpu().numpy()
+        for k in range(2):
+            assert np.array_equal(pk[k, :4], got[k][ranks[k, :4]].astype(np.float64)) and np.isnan(pk[k, 4:]).all()
+        # three segments of unequal length (the root of a three-rank exchange)
+        width = int(want_n.max())
+        pool = torch.full((2, 3, width), 9e9, dtype=rows.dtype, device="cuda")
+        seg_n = np.zeros((2, 3), dtype=np.int64)
+        for k in range(2):
+            cuts = [0, want_n[k] // 5, want_n[k] // 2, want_n[k]]
+            for g in range(3):
+                seg_n[k, g] = cuts[g + 1] - cuts[g]
+                pool[k, g, :seg_n[k, g]] = cand[k, cuts[g]:cuts[g + 1]]
+        seg_t = torch.from_numpy(seg_n).cuda()
+        _capi.check(lib, getattr(lib, f"fiveeq_select_pick_{sfx}")(2, 3, width, p(pool), p(seg_t), 6, p(ranks_t), p(picked), None))
+        assert np.array_equal(picked.cpu().numpy()[:, :4], pk[:, :4])
+    # argument checks on the host
+    z = ctypes.c_void_p(0x1000)
+    assert lib.fiveeq_select_bins_f64(1, 10, 10, z, z, 5000, z, z, 4, z, None) == _capi.E_INVALID
+    assert lib.fiveeq_select_bins_f64(1, 10, 5, z, z, 64, z, z, 4, z, None) == _capi.E_INVALID
+    assert lib.fiveeq_select_pick_f64(1, 0, 4, z, z, 2, z, z, None) == _capi.E_INVALID
+    assert lib.fiveeq_row_moments_f64(1, 0, 0, z, z, z, None) == _capi.E_INVALID
+
+
+def test_engine_summary_takes_its_moments_from_the_kernel_records():
+    from fiveeqscm_amd import emissions, params
+    from fiveeqscm_amd.engine import EnsembleEngine
+    N, steps = 70_001, [20, 59]
+    p = params.sample_ensemble_shard(params.default_params("multigas"), N, device="cuda:0")
+    E = emissions.rcp_like_emissions(750, 3)[200:260]
+    a = EnsembleEngine(p, N, E, device="cuda:0", output_steps=steps, store_concentrations=False, collect_stats=True)
+    a.run(mode="fused")
+    b = EnsembleEngine(p, N, E, device="cuda:0", output_steps=steps, store_concentrations=False)
+    b.run()
+    sa, sb = a.gather_summary(steps), b.gather_summary(steps)
+    T = b.T.cpu().numpy()
+    assert torch.equal(sa["percentiles"], sb["percentiles"])
+    np.testing.assert_allclose(sa["percentiles"].cpu().numpy(), np.percentile(T, (5.0, 50.0, 95.0), axis=1).T, rtol=1e-14)
+    for key in ("mean", "var", "min", "max"):
+        np.testing.assert_allclose(sa[key].cpu().numpy(), sb[key].cpu().numpy(), rtol=1e-9 if key == "var" else 1e-13)
+    np.testing.assert_allclose(sa["mean"].cpu().numpy(), T.mean(1), rtol=1e-13)
+    with pytest.raises(ValueError, match="not stored"):
+        a.gather_summary([3])
