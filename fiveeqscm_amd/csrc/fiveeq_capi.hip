@@ -557,6 +557,9 @@ const char* fiveeq_build_flags(void) {
 #if FIVEEQ_TILE_BLOCK != 1024
            " FIVEEQ_TILE_BLOCK=" FIVEEQ_STR(FIVEEQ_TILE_BLOCK)
 #endif
+#ifdef FIVEEQ_BIN_RULE_F64
+           " FIVEEQ_BIN_RULE_F64"
+#endif
 #if FIVEEQ_FUSED_CHUNK != 125
            " FIVEEQ_FUSED_CHUNK=" FIVEEQ_STR(FIVEEQ_FUSED_CHUNK)
 #endif
@@ -895,7 +898,7 @@ int fiveeq_hist_bins(int32_t n_rows, int64_t n_members, int64_t ld, const uint16
     if (!bins || !hist) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
     if (n_rows > 65535) return fail(FIVEEQ_E_INVALID, "n_rows=%d exceeds the 65535 rows of one launch", n_rows);
     int64_t chunk = hist_chunk(n_rows, n_members);
-    chunk = (chunk + 4 * FIVEEQ_BLOCK - 1) / (4 * FIVEEQ_BLOCK) * (4 * FIVEEQ_BLOCK);      // four members per lane and load
+    chunk = (chunk + 8 * FIVEEQ_BLOCK - 1) / (8 * FIVEEQ_BLOCK) * (8 * FIVEEQ_BLOCK);      // eight members per lane and load
     const int64_t chunks = (n_members + chunk - 1) / chunk;
     if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
     hipLaunchKernelGGL(fiveeq::hist_bins_kernel, dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,

@@ -739,32 +739,49 @@ constexpr unsigned short BIN_NAN = 0xFFFFu;
 //   bin = pos clamped to [0, n_bins - 1] and truncated; outliers land in the edge bins; a NaN has no bin (BIN_NAN).
 // Both forms are monotone in v (rounding is), which the summary's selection relies on: members of a lower bin are <= members
 // of a higher one.
+// The rule's three constants are plain values (an object with methods made the compiler park it in LDS — promote-alloca — in
+// the one-wave step kernel: 768 B of LDS, -1 wave/SIMD, +17 % on the per-step + bins form; measured, profiles/r04/ab_variants.txt).
 template <typename S> struct HistRule;
 template <> struct HistRule<double> {
     double lo, inv_w, top;
-    __device__ __forceinline__ HistRule(const double lo_, const double inv_w_, const int n_bins)
-        : lo(lo_), inv_w(inv_w_), top((double)(n_bins - 1)) {}
-    __device__ __forceinline__ unsigned int bin(const double v) const {
-        const double pos = (v - lo) * inv_w;
-        const unsigned int b = (unsigned int)(int)fmin(fmax(pos, 0.0), top);      // NaN pos -> 0 (fmax / fmin drop the NaN)
-        return v == v ? b : (unsigned int)BIN_NAN;
-    }
 };
 template <> struct HistRule<float> {
     float scale, offset, top;
-    __device__ __forceinline__ HistRule(const double lo_, const double inv_w_, const int n_bins)
-        : scale((float)inv_w_), offset((float)(-lo_ * inv_w_)), top((float)(n_bins - 1)) {}
-    __device__ __forceinline__ unsigned int of_pos(const float pos, const float v) const {
-        const unsigned int b = (unsigned int)(int)__builtin_amdgcn_fmed3f(pos, 0.0f, top);   // v_med3_f32: the clamp in one op
-        return v == v ? b : (unsigned int)BIN_NAN;
-    }
-    __device__ __forceinline__ unsigned int bin(const float v) const { return of_pos(__builtin_fmaf(v, scale, offset), v); }
-    __device__ __forceinline__ void bin2(const float2v v, unsigned int& b0, unsigned int& b1) const {   // v_pk_fma_f32
-        const float2v pos = __builtin_elementwise_fma(v, (float2v)scale, (float2v)offset);
-        b0 = of_pos(pos.x, v.x);
-        b1 = of_pos(pos.y, v.y);
-    }
+#ifdef FIVEEQ_BIN_RULE_F64
+    double lo64, inv_w64;                     // A/B builds only
+#endif
 };
+__device__ __forceinline__ HistRule<double> make_rule(const double, const double lo, const double inv_w, const int n_bins) {
+    return HistRule<double>{lo, inv_w, (double)(n_bins - 1)};
+}
+__device__ __forceinline__ HistRule<float> make_rule(const float, const double lo, const double inv_w, const int n_bins) {
+#ifdef FIVEEQ_BIN_RULE_F64
+    return HistRule<float>{(float)inv_w, (float)(-lo * inv_w), (float)(n_bins - 1), lo, inv_w};
+#else
+    return HistRule<float>{(float)inv_w, (float)(-lo * inv_w), (float)(n_bins - 1)};
+#endif
+}
+__device__ __forceinline__ unsigned int hist_bin(const HistRule<double> r, const double v) {
+    const double pos = (v - r.lo) * r.inv_w;
+    const unsigned int b = (unsigned int)(int)fmin(fmax(pos, 0.0), r.top);          // NaN pos -> 0 (fmax / fmin drop the NaN)
+    return v == v ? b : (unsigned int)BIN_NAN;
+}
+__device__ __forceinline__ unsigned int hist_bin_of_pos(const HistRule<float> r, const float pos, const float v) {
+    const unsigned int b = (unsigned int)(int)__builtin_amdgcn_fmed3f(pos, 0.0f, r.top);       // v_med3_f32: the clamp in one op
+    return v == v ? b : (unsigned int)BIN_NAN;
+}
+#ifndef FIVEEQ_BIN_RULE_F64
+__device__ __forceinline__ unsigned int hist_bin(const HistRule<float> r, const float v) {
+    return hist_bin_of_pos(r, __builtin_fmaf(v, r.scale, r.offset), v);
+}
+// two members of a packed lane: one v_pk_fma_f32; returns bin(v.x) | bin(v.y) << 16
+__device__ __forceinline__ unsigned int hist_bin2(const HistRule<float> r, const float2v v) {
+    const float2v pos = __builtin_elementwise_fma(v, (float2v)r.scale, (float2v)r.offset);
+    return hist_bin_of_pos(r, pos.x, v.x) | (hist_bin_of_pos(r, pos.y, v.y) << 16);
+}
+#else          // A/B builds only (tools/variants/bin_rule_f64.hpp): rounds 2-3's fp64 formula on fp32 rows
+#include "../../tools/variants/bin_rule_f64.hpp"
+#endif
 
 #ifdef FIVEEQ_STEP_WAVES
 #define FIVEEQ_STEP_ATTR __attribute__((amdgpu_waves_per_eu(FIVEEQ_STEP_WAVES, FIVEEQ_STEP_WAVES)))
@@ -837,14 +854,13 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
         }
         if constexpr (BINS) {                                            // the histogram bin of T, 2 bytes per member
             unsigned short* o = bin_ring + (int64_t)(t % ring_rows) * ld + m;
-            const HistRule<T> rule(hist_lo, hist_inv_w, n_bins);
+            const HistRule<T> rule = make_rule(T(0), hist_lo, hist_inv_w, n_bins);
             if constexpr (W == 1) {
-                *o = (unsigned short)rule.bin(Tn);
+                *o = (unsigned short)hist_bin(rule, Tn);
             } else {
-                unsigned int b0, b1;
-                rule.bin2(Tn, b0, b1);
-                if (full) *reinterpret_cast<unsigned int*>(o) = b0 | (b1 << 16);
-                else *o = (unsigned short)b0;
+                const unsigned int b01 = hist_bin2(rule, Tn);
+                if (full) *reinterpret_cast<unsigned int*>(o) = b01;
+                else *o = (unsigned short)(b01 & 0xffffu);
             }
         }
         }
@@ -905,7 +921,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     V* const tile = stat_tile[threadIdx.x >> 6];
     const int n_valid = (int)min((int64_t)64 * W, n - wave * 64 * W);               // members of this wave (<= 0: none)
     int ks = 0;                                                                      // steps parked in the tile
-    const HistRule<T> rule(hist_lo, hist_inv_w, n_bins);                             // (BINS only)
+    const HistRule<T> rule = make_rule(T(0), hist_lo, hist_inv_w, n_bins);           // (BINS only)
 
     FIVEEQ_HOOK_FUSED_BEGIN
     V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
@@ -948,12 +964,11 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
                 if (active) {
                     unsigned short* o = bin_ring + (int64_t)((tc + k) % ring_rows) * ld + m;     // scalar row offset
                     if constexpr (W == 1) {
-                        *o = (unsigned short)rule.bin(Tn);
+                        *o = (unsigned short)hist_bin(rule, Tn);
                     } else {
-                        unsigned int b0, b1;
-                        rule.bin2(Tn, b0, b1);
-                        if (full) *reinterpret_cast<unsigned int*>(o) = b0 | (b1 << 16);    // both members: one 4-byte store
-                        else *o = (unsigned short)b0;
+                        const unsigned int b01 = hist_bin2(rule, Tn);
+                        if (full) *reinterpret_cast<unsigned int*>(o) = b01;                // both members: one 4-byte store
+                        else *o = (unsigned short)(b01 & 0xffffu);
                     }
                 }
             }
@@ -1092,7 +1107,7 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
         if (threadIdx.x < NW) reinterpret_cast<T*>(&sh.km)[threadIdx.x] = src[threadIdx.x];
     }
     const KModel<T>& kmr = sh.km;
-    const HistRule<T> rule(hist_lo, hist_inv_w, n_bins);
+    const HistRule<T> rule = make_rule(T(0), hist_lo, hist_inv_w, n_bins);
     const int nt = t_end - t_begin;
     const int hw = (n_bins + 1) >> 1;
     const bool do_hist = hist != nullptr;
@@ -1165,12 +1180,11 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
                 }
                 if (do_hist) {
                     if constexpr (W == 1) {
-                        if (active) tile_hist_add(&h_s[k * hw], rule.bin(Tn));
+                        if (active) tile_hist_add(&h_s[k * hw], hist_bin(rule, Tn));
                     } else {
-                        unsigned int b0, b1;
-                        rule.bin2(Tn, b0, b1);
-                        if (active) tile_hist_add(&h_s[k * hw], b0);
-                        if (full) tile_hist_add(&h_s[k * hw], b1);
+                        const unsigned int b01 = hist_bin2(rule, Tn);
+                        if (active) tile_hist_add(&h_s[k * hw], b01 & 0xffffu);
+                        if (full) tile_hist_add(&h_s[k * hw], b01 >> 16);
                     }
                 }
                 if (wave_live) {
@@ -1285,6 +1299,10 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hfc_conc_kernel(
 // ---------------------------------------------------------------------------------
 constexpr int HIST_CHUNK_MIN = 16384;
 constexpr int HIST_MAX_BINS = 4096;
+// (Tried in round 4 and not kept: 2 or 4 SUB-HISTOGRAMS per workgroup, lane l counting into number l mod n, bank-shifted, to
+// spare the LDS atomic unit same-address collisions.  The passes got SLOWER — 5.4 -> 7.6 -> 13.4 us per 12.5M-member row of
+// bin indices — because the larger LDS footprint halves / quarters the resident waves: these passes run at the box's plain
+// copy rate for their access width and are bound by memory-level parallelism, not by LDS atomics.  profiles/r04/ab_variants.txt)
 
 template <typename T, bool MOM>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n, const int64_t ld, const int64_t chunk,
@@ -1307,9 +1325,9 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
     const T* x = rows + row * ld;
     const double inf = __builtin_inf();
     double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;      // MOM: this pass reads every value anyway, the moments ride along
-    const HistRule<T> rule(lo, inv_w, n_bins);
+    const HistRule<T> rule = make_rule(T(0), lo, inv_w, n_bins);
     auto count = [&](const T xv) {
-        const unsigned int b = rule.bin(xv);                                    // a NaN has no bin and is not counted
+        const unsigned int b = hist_bin(rule, xv);                                    // a NaN has no bin and is not counted
         const bool ok = b != (unsigned int)BIN_NAN;
         wave_lds_add(&h[ok ? b : 0u], 1u, ok ? b : ~0u);
         if constexpr (MOM) {
@@ -1373,23 +1391,41 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_bins_kernel(const int64_t n
     for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) h[b] = 0u;
     __syncthreads();
     const int64_t row = blockIdx.y;
-    const int64_t m0 = (int64_t)blockIdx.x * chunk;          // chunk is a multiple of 4 * FIVEEQ_BLOCK (host)
+    const int64_t m0 = (int64_t)blockIdx.x * chunk;          // chunk is a multiple of 8 * FIVEEQ_BLOCK (host)
     const int64_t m1 = min(m0 + chunk, n);
     const unsigned short* x = rows + row * ld;
     auto count = [&](const unsigned int b) {
         const bool ok = b < (unsigned int)n_bins;
         wave_lds_add(&h[ok ? b : 0u], 1u, ok ? b : ~0u);
     };
-    const bool wide = ((((uintptr_t)x) | ((uintptr_t)(ld * 2))) & 7) == 0;      // rows 8-byte aligned: 4 members per load
+    // rows 16-byte aligned: 8 members per lane and load (1 KiB per wave-instruction: the box copies 17 % faster at 16 than at
+    // 8 bytes per lane), two loads in flight, over the whole strides of 8 x 256 members; what is left of the chunk (fewer
+    // than 2048 members, only in the row's last chunk) goes one member per lane
+    const bool wide = ((((uintptr_t)x) | ((uintptr_t)(ld * 2))) & 15) == 0;
     int64_t m = m0 + (int64_t)threadIdx.x * 4;
     if (wide) {
-        for (; m + 3 < m1; m += 4 * FIVEEQ_BLOCK) {
-            const uint2 v = *reinterpret_cast<const uint2*>(x + m);
+        auto count8 = [&](const uint4 v) {
             count(v.x & 0xffffu);
             count(v.x >> 16);
             count(v.y & 0xffffu);
             count(v.y >> 16);
+            count(v.z & 0xffffu);
+            count(v.z >> 16);
+            count(v.w & 0xffffu);
+            count(v.w >> 16);
+        };
+        constexpr int64_t STRIDE = 8 * FIVEEQ_BLOCK;
+        const int64_t whole = m0 + (m1 - m0) / STRIDE * STRIDE;
+        int64_t m8 = m0 + (int64_t)threadIdx.x * 8;
+        for (; m8 + STRIDE < whole; m8 += 2 * STRIDE) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + m8);
+            const uint4 u = *reinterpret_cast<const uint4*>(x + m8 + STRIDE);
+            count8(v);
+            count8(u);
         }
+        if (m8 < whole) count8(*reinterpret_cast<const uint4*>(x + m8));
+        for (int64_t r = whole + threadIdx.x; r < m1; r += FIVEEQ_BLOCK) count(x[r]);
+        m = m1;
     }
     for (; m < m1; m += 4 * FIVEEQ_BLOCK)                     // unaligned rows, and the ragged tail of the last chunk
         for (int j = 0; j < 4 && m + j < m1; ++j) count(x[m + j]);
@@ -1542,7 +1578,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void select_bins_kernel(const int64_t
     }
     __syncthreads();
     const double lo = ranges[row * 2], hi = ranges[row * 2 + 1];
-    const HistRule<T> rule(lo, hi > lo ? (double)n_bins / (hi - lo) : 0.0, n_bins);       // pass 2's rule for this row, bit for bit
+    const HistRule<T> rule = make_rule(T(0), lo, hi > lo ? (double)n_bins / (hi - lo) : 0.0, n_bins);      // pass 2's rule for this row
     const int64_t m0 = (int64_t)blockIdx.x * chunk;             // chunk is a multiple of WN * FIVEEQ_BLOCK (host)
     const int64_t m1 = min(m0 + chunk, n);
     const T* x = rows + row * ld;
@@ -1551,7 +1587,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void select_bins_kernel(const int64_t
 
     // one value per lane: place it if its bin is marked.  `have` = this lane holds a member.
     auto take = [&](const T v, const bool have) {
-        const unsigned int b = rule.bin(v);
+        const unsigned int b = hist_bin(rule, v);
         const bool is_c = have && b != (unsigned int)BIN_NAN && ((mask_s[b >> 5] >> (b & 31u)) & 1u);
         const unsigned long long cm = __ballot(is_c);
         if (cm != 0ull) {                                        // wave-uniform; a few per cent of the wave-loads of a smooth row
