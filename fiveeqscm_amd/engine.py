@@ -33,8 +33,34 @@ INFINITY_CACHE_BYTES = 256 << 20     # MI355X die-level L3 (MI355X_MICROARCH.md)
 # The two box-dependent figures the schedules are derived from.  The defaults are what round 1-3 measured on MI355X; another
 # box (or a future driver) can set them from the environment, or measure them with `calibrate()` below, which overwrites these
 # module attributes — engines created afterwards use the new values.
-HBM_STREAM_BYTES_PER_S = float(os.environ.get("FIVEEQ_HBM_STREAM_BYTES_PER_S", 6.7e12))    # ceiling of the per-step kernel
-LAUNCH_BOUNDARY_S = float(os.environ.get("FIVEEQ_LAUNCH_BOUNDARY_S", 2.0e-6))              # dependent-launch boundary on one stream (measured 1.5-2.6 us)
+
+
+
+def _env_positive(name, default):
+    """A positive float from the environment; anything else (empty, garbage, zero, negative, nan) keeps the default, with a warning."""
+    raw = os.environ.get(name)
+    if raw is None:
+        return default
+    try:
+        val = float(raw)
+    except ValueError:
+        val = float("nan")
+    if not (val > 0.0) or val == float("inf"):
+        import warnings
+        warnings.warn(f"{name}={raw!r} is not a positive number: using the default {default:g}")
+        return default
+    return val
+
+
+def _env_choice(name, default, choices):
+    raw = os.environ.get(name, default)
+    if raw not in choices:
+        raise ValueError(f"{name}={raw!r}: must be one of {sorted(choices)}")
+    return raw
+
+
+HBM_STREAM_BYTES_PER_S = _env_positive("FIVEEQ_HBM_STREAM_BYTES_PER_S", 6.7e12)    # ceiling of the per-step kernel (DESIGN.md section 4)
+LAUNCH_BOUNDARY_S = _env_positive("FIVEEQ_LAUNCH_BOUNDARY_S", 2.0e-6)              # dependent-launch boundary on one stream (measured 1.5-2.6 us)
 PER_STEP_SPLIT_MIN_S = 16.0e-6       # a per-step launch is split over two streams from this much traffic time on
 PER_STEP_BLOCK = 25                  # steps enqueued per part before switching to the next part's stream
 FUSED_SPAN_STEPS = 128               # mode='fused': steps per launch for ensembles of few rounds of waves (see fused_span)
@@ -198,6 +224,9 @@ class EnsembleEngine:
             # per-step (count, sum, sum^2, min, max) produced by the streamed histogram pass instead of the kernels
             self._step_sums = (torch.zeros((self.n_steps, 5), dtype=torch.float64, device=dev) if collect_stats else None)
             self._step_sums_valid = np.zeros(self.n_steps, dtype=bool)
+            # steps whose moments THIS engine holds (wave records written by its launches, or records / folded sums restored
+            # from a checkpoint): only these are saved as valid by state_dict("summaries")
+            self._stats_have = np.zeros(self.n_steps, dtype=bool)
             self.hist_spec = None
             self.T_hist = None
             if hist is not None:
@@ -214,7 +243,7 @@ class EnsembleEngine:
             self.hist_ring_steps = max(1, min(int(hist_ring_steps), self.n_steps))
             # where the streamed pipeline's histogram pass runs: "side" = a second HIP stream beside the next chunk's fused
             # kernel, "same" = behind each chunk on the caller's stream (see _run_fused_streamed_hist)
-            self.hist_pass_stream = os.environ.get("FIVEEQ_HIST_PASS_STREAM", "side")
+            self.hist_pass_stream = _env_choice("FIVEEQ_HIST_PASS_STREAM", "side", ("side", "same"))
             if hist_ring not in ("bins", "T"):
                 raise ValueError("hist_ring must be 'bins' or 'T'")
             self.hist_ring = hist_ring
@@ -236,6 +265,7 @@ class EnsembleEngine:
         self._R0 = None if R0 is None else np.asarray(R0, dtype=np.float64).reshape(SP, N)
         self._S0 = None if S0 is None else np.asarray(S0, dtype=np.float64).reshape(2, N)
         self.t_next = 0                     # first step not yet run (bookkeeping for checkpoints)
+        self.last_mode = None               # the mode the last run() used after resolving 'auto'
         self.reset_state()
         self._plans = {}
 
@@ -290,6 +320,7 @@ class EnsembleEngine:
         if self.T_hist is not None:
             self.T_hist.zero_()
         self._step_sums_valid[:] = False
+        self._stats_have[:] = False
         self.t_next = 0
 
     def state_dict(self, include_outputs="summaries"):
@@ -315,11 +346,15 @@ class EnsembleEngine:
             if self.T_hist is not None:
                 out["T_hist"] = self.T_hist.cpu().numpy()
             if self.collect_stats:
+                # only the steps this engine HAS moments for (it ran them, or a checkpoint brought them): a run that began
+                # at t_begin > 0, or a state-only checkpoint loaded before it, leaves the earlier steps out — their
+                # zero-filled records are not moments
                 sums = np.zeros((self.n_steps, 5), dtype=np.float64)
-                valid = np.zeros(self.n_steps, dtype=bool)
-                if self.t_next > 0:
-                    sums[:self.t_next] = self.stats_sums(0, self.t_next).cpu().numpy()
-                    valid[:self.t_next] = True
+                valid = self._stats_have.copy()
+                if valid.any():
+                    lo_t, hi_t = int(np.nonzero(valid)[0][0]), int(np.nonzero(valid)[0][-1]) + 1
+                    sums[lo_t:hi_t] = self.stats_sums(lo_t, hi_t).cpu().numpy()
+                    sums[~valid] = 0.0
                 out["_step_sums"], out["_step_sums_valid"] = sums, valid
         if include_outputs is True:
             for name in ("T_stats", "C", "T"):
@@ -341,8 +376,12 @@ class EnsembleEngine:
             dst.copy_(torch.from_numpy(src).to(self.dtype))
         self.t_next = int(state.get("t_next", 0))
         self._step_sums_valid[:] = False
+        self._stats_have[:] = False
         if "_step_sums_valid" in state and self._step_sums is not None:
             self._step_sums_valid[:] = np.asarray(state["_step_sums_valid"], dtype=bool)
+            self._stats_have[:] = self._step_sums_valid
+        if "T_stats" in state and self.collect_stats:          # raw wave records: every step before t_next was run by the saver
+            self._stats_have[:self.t_next] = True
         if self.T_hist is not None and "T_hist" not in state:
             self.T_hist.zero_()
         if "T_stats" in state:
@@ -399,10 +438,16 @@ class EnsembleEngine:
 
     def step(self, t, stream=None):
         """One timestep = one kernel launch (asynchronous)."""
+        if self._ps_unjoined:                         # a run(..., join=False) may still be writing R, S, T_stats on the side streams
+            self.join(stream)
+        self._step_sums_valid[int(t)] = False         # this launch writes the step's wave record: older folded moments are stale
+        if self.collect_stats:
+            self._stats_have[int(t)] = True
         if self.concentration_driven:
             self._wave_stats()
             with torch.cuda.device(self.device):
                 _capi.check(self.lib, self._run_inverse(t, t + 1, stream))
+            self.t_next = int(t) + 1
             return
         N = self.n_members
         fn = getattr(self.lib, f"fiveeq_step_{self._sfx}")
@@ -425,7 +470,9 @@ class EnsembleEngine:
                    state crosses HBM once per k_steps — the per-step family's answer for small ensembles;
         'tiled'    the time-tiled persistent kernel, `k_steps` steps per launch (None/0: the largest tile
                    that fits the LDS); accumulates `T_hist` inside the time loop if the engine has `hist=`;
-        'auto'     'per_step' while a step's HBM traffic hides the launch boundary, else 'ksteps'.
+        'auto'     'per_step' while a step's HBM traffic hides the launch boundary, else 'ksteps' — or, on an engine with
+                   hist=, 'fused' (the streamed histogram pipeline), the fastest form that fills T_hist on a launch-bound
+                   ensemble (profiles/r04/auto_hist_table.txt).
         Every mode gives bit-identical results.
         join=False (mode 'per_step' on several streams only): do not make the caller's stream wait for the side streams at
         the end, and do not make the side streams wait for the caller's stream at the start of the NEXT such call — for
@@ -438,10 +485,17 @@ class EnsembleEngine:
             k_steps = self.auto_k_steps() if k_steps is None else int(k_steps)
             if k_steps <= 1:
                 mode = "per_step"
-            elif self.T_hist is not None:                # the K-step form that carries histograms is the tiled kernel
-                mode, k_steps = "tiled", min(k_steps, self.tile_steps())
+            elif self.T_hist is not None:
+                # Launch-bound AND filling T_hist: the streamed pipeline (the fused kernel in chunks of hist_ring_steps steps
+                # + the histogram pass) — measured against the other two forms that fill T_hist, us per step at 10k / 100k
+                # members, 4096 bins, fp64: 1.6 / 2.5 against per-step + bins 4.2 / 6.4 and the tiled kernel at the auto K
+                # 4.4 / 10.6 (its persistent grid and per-launch flush need long tiles and millions of members); same table
+                # for fp32 and 1024 bins: profiles/r04/auto_hist_table.txt, DESIGN.md section 3.5.  Rounds 2-3 sent these
+                # ensembles to the tiled kernel.
+                mode, k_steps = "fused", None
             else:
                 mode = "ksteps"
+        self.last_mode = mode            # what 'auto' resolved to (tests, bench.py's config.mode_resolved)
         if self.T_hist is not None and mode in ("graph", "ksteps"):
             raise ValueError(f"mode {mode!r} does not fill T_hist: use 'fused', 'tiled' or 'per_step' with hist=")
         with torch.cuda.device(self.device):
@@ -449,6 +503,8 @@ class EnsembleEngine:
                 self._wave_stats()
                 # these launches write per-wave records: moments an earlier streamed pass left for the same steps are stale
                 self._step_sums_valid[int(t_begin):t_end] = False
+            if self.collect_stats:
+                self._stats_have[int(t_begin):t_end] = True
             if self.concentration_driven:
                 rc = self._run_inverse(t_begin, t_end, stream)
             elif mode == "per_step" and self.T_hist is not None:
@@ -618,7 +674,7 @@ class EnsembleEngine:
         its strip into T_hist (fiveeq_hist_bins) on its own stream.  2 bytes written + 2 read per member-step on top of the
         step's 124 / 248."""
         N = self.n_members
-        ring = self._bin_ring()
+        ring = self._bin_ring(slots=1)
         S = ring["S"]
         buf = ring["buf"][0]
         run = getattr(self.lib, f"fiveeq_run_bins_{self._sfx}")
@@ -647,14 +703,16 @@ class EnsembleEngine:
             streams[0].wait_stream(s_)
         return rc
 
-    def _bin_ring(self):
-        """Two-slot ring [2, S, N] of uint16 bin indices for the streamed histograms (hist_ring='bins')."""
+    def _bin_ring(self, slots=2):
+        """Ring [slots, S, N] of uint16 bin indices for the streamed histograms (hist_ring='bins'): mode 'fused'
+        double-buffers (two slots), mode 'per_step' counts each strip right behind its steps (one slot: half the memory,
+        1.6 GB instead of 3.2 at 12.5M members and S = 64); grown to two slots when a fused run follows a per-step one."""
         N, S, dev = self.n_members, max(1, min(int(self.hist_ring_steps), self.n_steps)), self.device
         ring = self._bins
-        if ring is None or ring["S"] != S:
+        if ring is None or ring["S"] != S or ring["buf"].shape[0] < slots:
             torch.cuda.synchronize(dev)
             self._bins = None
-            self._bins = ring = {"S": S, "buf": torch.empty((2, S, N), dtype=torch.int16, device=dev),
+            self._bins = ring = {"S": S, "buf": torch.empty((slots, S, N), dtype=torch.int16, device=dev),
                                  "side": torch.cuda.Stream(device=dev), "drained": [torch.cuda.Event(), torch.cuda.Event()]}
         return ring
 
@@ -802,6 +860,8 @@ class EnsembleEngine:
         (fiveeqscm_amd.distributed.reduce_stats)."""
         if not self.collect_stats:
             raise RuntimeError("engine was built with collect_stats=False")
+        if self._ps_unjoined:
+            self.join()
         t_end = self.n_steps if t_end is None else int(t_end)
         valid = self._step_sums_valid[t_begin:t_end]
         if valid.all():                                          # everything came from the histogram pass
@@ -846,6 +906,8 @@ class EnsembleEngine:
         several calls / shards accumulate; percentiles: distributed.histogram_percentiles."""
         if self.T is None:
             raise RuntimeError("no stored T rows to histogram")
+        if self._ps_unjoined:
+            self.join(stream)
         x = self.T if rows is None else self.T[rows].contiguous()
         k = x.shape[0]
         if out is None:
@@ -863,6 +925,8 @@ class EnsembleEngine:
         percentiles near that tail (compare with stats()['min'/'max'])."""
         if self.T_hist is None:
             raise RuntimeError("engine was built without hist=")
+        if self._ps_unjoined:
+            self.join()
         return torch.stack([self.T_hist[:, 0], self.T_hist[:, -1]], dim=1)
 
     # -- accounting ----------------------------------------------------------------------

@@ -268,3 +268,30 @@ def test_abi_v6_bin_ring_entry_points_validate_on_the_host():
     assert count(2, 9, 8, p, 16, p) == _capi.E_INVALID and count(2, 8, 8, p, 0, p) == _capi.E_INVALID
     assert count(2, 8, 8, None, 16, p) == _capi.E_INVALID and count(2, 8, 8, p, 16, None) == _capi.E_INVALID
     assert count(70000, 8, 8, p, 16, p) == _capi.E_INVALID and count(0, 8, 8, None, 16, None) == _capi.OK
+
+
+def test_engine_module_validates_its_environment():
+    """FIVEEQ_HBM_STREAM_BYTES_PER_S / FIVEEQ_LAUNCH_BOUNDARY_S: garbage, zero or negative values keep the defaults with a
+    warning instead of breaking the import or dividing by zero later; FIVEEQ_HIST_PASS_STREAM accepts 'side' / 'same' only."""
+    import subprocess
+    import sys
+    code = ("import warnings; warnings.simplefilter('error'); import fiveeqscm_amd.engine as e; "
+            "print(e.HBM_STREAM_BYTES_PER_S, e.LAUNCH_BOUNDARY_S)")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FIVEEQ_")}
+    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                        env=dict(env, FIVEEQ_HBM_STREAM_BYTES_PER_S="5e12", FIVEEQ_LAUNCH_BOUNDARY_S="3e-6"))
+    assert ok.returncode == 0 and ok.stdout.split() == ["5000000000000.0", "3e-06"], ok.stderr
+    for bad in ("", "abc", "0", "-2e-6", "nan", "inf"):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                             env=dict(env, FIVEEQ_LAUNCH_BOUNDARY_S=bad))
+        assert out.returncode != 0 and "not a positive number" in out.stderr, (bad, out.stderr)      # the warning, made an error
+        soft = subprocess.run([sys.executable, "-W", "ignore", "-c", code.replace("warnings.simplefilter('error'); ", "")],
+                              capture_output=True, text=True, cwd=ROOT, env=dict(env, FIVEEQ_LAUNCH_BOUNDARY_S=bad))
+        assert soft.returncode == 0 and soft.stdout.split()[1] == "2e-06", (bad, soft.stderr)
+    from fiveeqscm_amd import engine
+    with pytest.raises(ValueError, match="FIVEEQ_HIST_PASS_STREAM"):
+        os.environ["FIVEEQ_HIST_PASS_STREAM"] = "sidee"
+        try:
+            engine._env_choice("FIVEEQ_HIST_PASS_STREAM", "side", ("side", "same"))
+        finally:
+            del os.environ["FIVEEQ_HIST_PASS_STREAM"]

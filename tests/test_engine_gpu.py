@@ -1413,3 +1413,114 @@ def test_fused_span_relaunch_is_bit_identical(gpu, monkeypatch):
     big.close()
     with pytest.raises(ValueError):
         _engine(p, N, E, fused_span=0)
+
+
+def test_auto_with_histograms_picks_what_the_measured_table_says(gpu):
+    """profiles/r04/auto_hist_table.json: on a launch-bound ensemble the streamed pipeline (mode 'fused') fills T_hist 2-4x
+    faster than per-step + bins and than the tiled kernel at the auto K, so that is what mode='auto' resolves to on an
+    engine with hist=; a bandwidth-bound ensemble keeps the per-step kernel (the north-star form).  Whatever it picks, the
+    results are those of the explicit per-step run, bit for bit."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r04", "auto_hist_table.json")) as fh:
+        table = json.load(fh)
+    for dt in ("f64", "f32"):
+        for nb in ("4096", "1024"):
+            for n in ("10000", "100000"):
+                row = table[dt][nb][n]
+                assert row["auto_k_steps"] > 1
+                others = [v for k, v in row.items() if k != "auto_k_steps" and k != "fused+bin ring"]
+                assert row["fused+bin ring"] < min(others), (dt, nb, n, row)
+    n_steps = 90
+    E = emi.rcp_like_emissions(n_steps, 3)
+    for N, want_mode in ((20_000, "fused"), (1_000_000, "per_step")):
+        p = prm.sample_ensemble_shard(prm.default_params("multigas"), N, device="cuda:0")
+        a = _engine(p, N, E, hist=(-1.0, 6.0, 1024), hist_ring_steps=32)
+        assert (a.auto_k_steps() > 1) == (want_mode == "fused")
+        a.run(mode="auto")
+        assert a.last_mode == want_mode
+        b = _engine(p, N, E, hist=(-1.0, 6.0, 1024), hist_ring_steps=32)
+        b.run(mode="per_step")
+        torch.cuda.synchronize()
+        assert torch.equal(a.T_hist, b.T_hist) and torch.equal(a.T, b.T) and torch.equal(a.C, b.C) and torch.equal(a.R, b.R)
+        assert int(a.T_hist.sum()) == N * n_steps
+        a.close(), b.close()
+        del a, b
+
+
+def test_summaries_in_a_checkpoint_cover_only_the_steps_the_engine_has_moments_for(gpu):
+    """state_dict('summaries') marks a step's moments valid only if this engine ran the step (or a checkpoint brought its
+    moments): a run that starts late, or follows a state-only checkpoint, must not save the zero-filled records of the steps
+    before it as real moments (advisor, round 3)."""
+    N, n_steps = 3000, 60
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    whole = _engine(p, N, E, collect_stats=True, store_trajectory=False)
+    whole.run(0, 40)
+    want = whole.stats_sums(0, 40).cpu().numpy()
+    late = _engine(p, N, E, collect_stats=True, store_trajectory=False)
+    late.load_state_dict(whole.state_dict(include_outputs=False))          # state only: no moments of steps [0, 40)
+    late.run(40, n_steps)
+    ck = late.state_dict()
+    assert ck["_step_sums_valid"].tolist() == [False] * 40 + [True] * 20 and not ck["_step_sums"][:40].any()
+    whole.run(40, n_steps)
+    np.testing.assert_array_equal(ck["_step_sums"][40:], whole.stats_sums(40, n_steps).cpu().numpy())
+    full = whole.state_dict()
+    assert full["_step_sums_valid"].all()
+    np.testing.assert_array_equal(full["_step_sums"][:40], want)
+    third = _engine(p, N, E, collect_stats=True, store_trajectory=False)
+    third.load_state_dict(whole.state_dict())                               # summaries travel: the loader has all 60 steps
+    assert third.state_dict()["_step_sums_valid"].all()
+    fresh = _engine(p, N, E, collect_stats=True, store_trajectory=False)
+    fresh.run(10, 20)
+    assert fresh.state_dict()["_step_sums_valid"].tolist() == [False] * 10 + [True] * 10 + [False] * 40
+    for e in (whole, late, third, fresh):
+        e.close()
+
+
+def test_step_and_the_readers_join_an_unjoined_run(gpu):
+    """run(..., join=False) leaves work on the side streams; step() and the readers (stats_sums, T_histogram,
+    hist_edge_counts) must wait for it themselves, and step() must drop folded moments of the step it overwrites."""
+    N, n_steps = 600_000, 40
+    p = prm.sample_ensemble_shard(prm.default_params("multigas"), N, device="cuda:0")
+    E = emi.rcp_like_emissions(n_steps, 3)
+    a = _engine(p, N, E, collect_stats=True, per_step_streams=2)
+    assert len(a.per_step_stream_list()) == 2
+    a.run(0, 30, join=False)
+    assert a._ps_unjoined
+    for t in range(30, n_steps):
+        a.step(t)                                        # joins first: the side stream's part of R, S is complete
+    assert not a._ps_unjoined
+    b = _engine(p, N, E, collect_stats=True, per_step_streams=1)
+    b.run()
+    torch.cuda.synchronize()
+    for name in ("C", "T", "R", "S"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.stats_sums(), b.stats_sums())
+    a.reset_state()
+    a.run(0, n_steps, join=False)
+    sums = a.stats_sums()                                # a reader right behind an unjoined run
+    h = a.T_histogram(-1.0, 6.0, 256)
+    assert not a._ps_unjoined and torch.equal(sums, b.stats_sums()) and torch.equal(h, b.T_histogram(-1.0, 6.0, 256))
+    a._step_sums_valid[5] = True                         # pretend a streamed pass left folded moments for step 5
+    a._step_sums[5] = -1.0
+    a.reset_state()
+    for t in range(6):
+        a.step(t)
+    assert not a._step_sums_valid[5] and torch.equal(a.stats_sums(0, 6), b.stats_sums(0, 6))
+    a.close(), b.close()
+
+
+def test_per_step_histograms_use_a_one_slot_bin_ring(gpu):
+    N, n_steps = 50_000, 40
+    p = prm.sample_ensemble_shard(prm.default_params("multigas"), N, device="cuda:0")
+    E = emi.rcp_like_emissions(n_steps, 3)
+    a = _engine(p, N, E, hist=(-1.0, 6.0, 512), hist_ring_steps=16, store_trajectory=False)
+    a.run(mode="per_step")
+    assert tuple(a._bins["buf"].shape) == (1, 16, N)     # half the ring of the double-buffered fused pipeline
+    per_step = a.T_hist.clone()
+    a.reset_state()
+    a.run(mode="fused")
+    assert tuple(a._bins["buf"].shape) == (2, 16, N) and torch.equal(a.T_hist, per_step)
+    a.close()
