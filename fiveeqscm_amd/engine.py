@@ -238,7 +238,10 @@ class EnsembleEngine:
                 self.hist_spec = (lo_h, hi_h, nb)
                 self.T_hist = torch.zeros((self.n_steps, nb), dtype=torch.int64, device=dev)
             if hist_ring_steps == "auto":      # as long as 8 GB of ring allow, at most 128 steps: every chunk boundary
-                w_ = 8 if dtype == torch.float64 else 4       # costs one state + parameter round trip through HBM
+                # costs one state + parameter round trip through HBM.  A ring entry is a 2-byte bin index (hist_ring='bins')
+                # or a T value (hist_ring='T'): 12.5M fp32 members get 2 x 128 steps of bin indices (6.4 GB) where the T ring
+                # stops at 2 x 85 — and the streamed histograms cost +18-20 % instead of +21-23 % (profiles/r04).
+                w_ = 2 if hist_ring == "bins" else (8 if dtype == torch.float64 else 4)
                 hist_ring_steps = min(128, max(8, (8 << 30) // (2 * N * w_)))
             self.hist_ring_steps = max(1, min(int(hist_ring_steps), self.n_steps))
             # where the streamed pipeline's histogram pass runs: "side" = a second HIP stream beside the next chunk's fused

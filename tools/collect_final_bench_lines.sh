@@ -1,11 +1,12 @@
 #!/usr/bin/env bash
-# Run ON THE GPU BOX (via gpurun) from the repo root, AFTER `tools/collect_profiles.sh r03 quick` has produced the
+# Run ON THE GPU BOX (via gpurun) from the repo root, AFTER `tools/collect_profiles.sh <tag> quick` has produced the
 # counter files and they were copied to profiles/: re-collects the fp32 SQ passes (instructions, packed share), merges
-# them into profiles/valu.json, then regenerates EVERY bench line and the kernel trace under gpurun_out/r03k/, so that no
+# them into profiles/valu.json, then regenerates EVERY bench line and the kernel trace under gpurun_out/<tag>k/, so that no
 # committed bench line was produced with an older valu.json / traffic.json than the one committed beside it.
 # rocprofv3 is always given `python3 script` directly after `--`; --pmc passes carry --kernel-trace only.
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03k; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+TAG=${1:-r04}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/${TAG}k; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 cp $R/profiles/valu.json $OUT/valu.json
 SQA="SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 SQB="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM"

@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: produces every measurement DESIGN.md quotes
-# under gpurun_out/<tag>/.  Usage: bash tools/collect_profiles.sh r03 [quick|rest]
+# under gpurun_out/<tag>/.  Usage: bash tools/collect_profiles.sh r04 [quick|rest]
 # (quick = the default bench line, the kernel trace and every PMC pass; rest = the other bench lines and the sweeps)
 # rocprofv3 is always given the program itself after `--` (python3 script), never a shell or env wrapper, and the
 # --pmc passes carry --kernel-trace only (no sys/hip/hsa trace domains).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
@@ -73,6 +73,5 @@ python3 $R/tools/tiled_hist_bench.py --small 2>&1 | grep -v amdgpu.ids > $OUT/in
 python3 $R/tools/tiled_hist_bench.py --members 1000000 --dtype f64 2>&1 | grep -v amdgpu.ids > $OUT/in_loop_hist_1M_f64.txt
 python3 $R/tools/config5_demo.py 2>&1 | grep -v amdgpu.ids > $OUT/config5_shard_end_to_end.txt
 python3 $R/tools/packed_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/packed_ab.txt
-[ -f $R/build_variants/libfiveeq_r02.so ] && python3 $R/tools/r02_vs_r03.py 2>&1 | grep -v amdgpu.ids > $OUT/r02_vs_r03.txt
 fi
 ls $OUT

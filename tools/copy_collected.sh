@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
 # Run in the build container after `gpurun -- bash tools/collect_profiles.sh r03` (and again after
-# tools/collect_final_bench_lines.sh): copies what is judged from the scratch gpurun_out/<tag>/ into profiles/r03/ (and the two
-# counter files bench.py reads into profiles/).   Usage: bash tools/copy_collected.sh [r03|r03k]
+# tools/collect_final_bench_lines.sh): copies what is judged from the scratch gpurun_out/<tag>/ into profiles/<round>/ (and the
+# two counter files bench.py reads into profiles/).   Usage: bash tools/copy_collected.sh [r04|r04k]
 set -u
-TAG=${1:-r03}; S=gpurun_out/$TAG; D=profiles/r03
+TAG=${1:-r04}; S=gpurun_out/$TAG; D=profiles/${TAG%k}; mkdir -p $D
 for f in $S/bench_*.json $S/sq_counters_*.csv; do [ -f "$f" ] && cp "$f" $D/; done
-[ "$TAG" = r03 ] && for f in $S/*.txt; do [ -f "$f" ] && cp "$f" $D/; done     # the tables come from collect_profiles.sh only
+[ "$TAG" = "${TAG%k}" ] && for f in $S/*.txt; do [ -f "$f" ] && cp "$f" $D/; done     # the tables come from collect_profiles.sh only
 for f in valu.json traffic.json; do [ -f $S/$f ] && cp $S/$f $D/$f && cp $S/$f profiles/$f; done
 for n in fetch_1000000 write_1000000 fetch_8000000 write_8000000 fetch_fused write_fused; do
   src=$(ls -t $S/pmc_$n/*/*counter_collection.csv 2>/dev/null | head -1)
