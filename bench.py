@@ -374,7 +374,7 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
-    dist, data_group = None, None
+    dist, data_group, tmo = None, None, None
     # FIVEEQ_BENCH_FORCE_DIST=1: build the process groups and run every collective of the N > 1 path (barriers, the MAX
     # of the block times, the summary exchange) in a ONE-rank job too — RCCL first contact for this file on a one-GPU box.
     force_dist = world == 1 and os.environ.get("FIVEEQ_BENCH_FORCE_DIST") == "1"
@@ -395,8 +395,8 @@ def main():
         tmo = timedelta(seconds=a.dist_timeout_s)
         with _stdout_to_stderr():          # gloo announces its connections on STDOUT: the one line must stay the only one
             dist.init_process_group("gloo", timeout=tmo)
-            data_group = dist.new_group(backend="nccl", timeout=tmo) if backend == "nccl" else dist.group.WORLD
             dist.barrier()
+        # (the RCCL group itself is created where it is first used: inside the watchdog-protected summary section below)
 
     from fiveeqscm_amd import emissions, params
     from fiveeqscm_amd.distributed import gather_summary, shard_bounds
@@ -824,6 +824,8 @@ def main():
             if os.environ.get("FIVEEQ_BENCH_HANG_SUMMARY") == str(rank):     # test hook: this rank never enters the exchange
                 time.sleep(10 * a.summary_watchdog_s + 60)
             summary_stats = {}
+            if dist is not None:               # data plane: RCCL ("nccl" on ROCm); its communicator comes up with the first collective
+                data_group = dist.new_group(backend="nccl", timeout=tmo) if backend == "nccl" else dist.group.WORLD
             gather_summary(rows, percentiles=(5.0, 50.0, 95.0), group=data_group)       # warm: communicator + library set-up
             sync_all()
             ts = time.perf_counter()

@@ -1,11 +1,12 @@
-"""Every number DESIGN.md quotes from a tracked JSON file must be IN that file.
+"""Every number DESIGN.md (the design as built, round 4) and profiles/r03/NOTES.md (round 3's text with its A/B history) quote
+from a tracked JSON file must be IN that file.
 
 A cell that quotes a measurement writes it as   **number** (`file.json[key].field.sub` / scale)   — the bold number, then in
-backticks the tracked file (under profiles/ or profiles/r03/), an optional top-level [key] (keys of valu.json / traffic.json
+backticks the tracked file (under profiles/r04/, then profiles/; NOTES.md: under profiles/r03/), an optional top-level [key] (keys of valu.json / traffic.json
 contain ':' and ','), a dotted path, and an optional '/ scale' or 'x scale'.  This test parses all of them and fails on a
 mismatch beyond the rounding of the printed digits (plus 0.2 %), so that the document cannot drift from the files the way
 round 2's did (391 vs 374.4 VALU per wave-step).  It also pins profiles/valu.json and profiles/traffic.json — the copies
-bench.py reads — to the round's collection under profiles/r03/."""
+bench.py reads — to the round's collection under profiles/r04/."""
 import json
 import os
 import re
@@ -17,12 +18,16 @@ CITE = re.compile(r"\*\*(?P<num>[-+]?[0-9][0-9.,]*(?:e[-+]?[0-9]+)?)\*\*[^`|\n]{
 LOOSE = re.compile(r"\*\*[-+]?[0-9][0-9.,e+-]*\*\*[^`|\n]{0,60}?\(`[A-Za-z0-9_./-]+\.json")
 
 
-def _resolve(name):
-    for base in ("profiles", os.path.join("profiles", "r03"), ""):
+DOCS = {"DESIGN.md": (os.path.join("profiles", "r04"), "profiles"),
+        os.path.join("profiles", "r03", "NOTES.md"): (os.path.join("profiles", "r03"),)}
+
+
+def _resolve(name, bases):
+    for base in bases:
         path = os.path.join(ROOT, base, name)
         if os.path.exists(path):
             return path
-    raise AssertionError(f"DESIGN.md cites {name}, which is not a tracked file under profiles/")
+    raise AssertionError(f"{name} is cited but is not a tracked file under {bases}")
 
 
 def _lookup(doc, key, path):
@@ -33,11 +38,15 @@ def _lookup(doc, key, path):
     return float(doc)
 
 
-def test_design_md_numbers_are_in_the_files_they_cite():
-    with open(os.path.join(ROOT, "DESIGN.md")) as fh:
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("doc", sorted(DOCS))
+def test_document_numbers_are_in_the_files_they_cite(doc):
+    with open(os.path.join(ROOT, doc)) as fh:
         text = fh.read()
     cites = list(CITE.finditer(text))
-    assert len(cites) >= 12, f"only {len(cites)} file-backed numbers found in DESIGN.md: the citation format changed?"
+    assert len(cites) >= 12, f"only {len(cites)} file-backed numbers found in {doc}: the citation format changed?"
     assert len(cites) == len(LOOSE.findall(text)), "a bold number cites a .json file in a form this test cannot parse"
     # ... and a citation that sits on the NEXT line, or further than 60 characters behind its number, is not parsed either: a
     # bold number whose following text reaches a backticked .json path before the next bold number must be a parsed one
@@ -47,11 +56,11 @@ def test_design_md_numbers_are_in_the_files_they_cite():
             continue
         tail = text[m.end():m.end() + 200].split("**")[0]
         assert not re.search(r"\(`[A-Za-z0-9_./-]+\.json", tail), (
-            f"DESIGN.md line {text.count(chr(10), 0, m.start()) + 1}: {m.group(0)} is followed by a .json citation this test does "
+            f"{doc} line {text.count(chr(10), 0, m.start()) + 1}: {m.group(0)} is followed by a .json citation this test does "
             f"not parse (put `(file.json.path)` right behind the number, on the same line)")
     cache, bad = {}, []
     for m in cites:
-        path = _resolve(m["file"])
+        path = _resolve(m["file"], DOCS[doc])
         if path not in cache:
             with open(path) as fh:
                 cache[path] = json.load(fh)
@@ -67,11 +76,16 @@ def test_design_md_numbers_are_in_the_files_they_cite():
         exp = float("1" + shown[shown.index("e"):]) if "e" in shown else 1.0
         tol = 0.5 * 10.0 ** (-digits) * exp + 2e-3 * abs(val)
         if abs(float(shown) - val) > tol:
-            bad.append(f"DESIGN.md says {shown}, {m['file']}{'[' + m['key'] + ']' if m['key'] else ''}{m['path']} holds {val:.6g}")
+            bad.append(f"{doc} says {shown}, {m['file']}{'[' + m['key'] + ']' if m['key'] else ''}{m['path']} holds {val:.6g}")
     assert not bad, "\n".join(bad)
 
 
 def test_bench_reads_this_rounds_counter_files():
     for name in ("valu.json", "traffic.json"):
-        with open(os.path.join(ROOT, "profiles", name)) as a, open(os.path.join(ROOT, "profiles", "r03", name)) as b:
-            assert json.load(a) == json.load(b), f"profiles/{name} is not profiles/r03/{name}"
+        with open(os.path.join(ROOT, "profiles", name)) as a, open(os.path.join(ROOT, "profiles", "r04", name)) as b:
+            assert json.load(a) == json.load(b), f"profiles/{name} is not profiles/r04/{name}"
+
+
+def test_design_md_stays_a_design_document():
+    """The design as built in at most 20 KB (review, round 3: 59 KB, half of it A/B history — that lives in profiles/r0N/ now)."""
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 20 * 1024

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: produces every measurement DESIGN.md quotes
-# under gpurun_out/<tag>/.  Usage: bash tools/collect_profiles.sh r04 [quick|rest]
+# under gpurun_out/<tag>/.  Usage: bash tools/collect_profiles.sh r04 [quick|rest|sweeps]
 # (quick = the default bench line, the kernel trace and every PMC pass; rest = the other bench lines and the sweeps)
 # rocprofv3 is always given the program itself after `--` (python3 script), never a shell or env wrapper, and the
 # --pmc passes carry --kernel-trace only (no sys/hip/hsa trace domains).
@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-if [ "$QUICK" != "rest" ]; then
+if [ "$QUICK" != "rest" ] && [ "$QUICK" != "sweeps" ]; then
 echo "== bench (default workload) =="
 python3 $R/bench.py > $OUT/bench_config3.json 2> $OUT/bench_config3.err || echo "bench failed"
 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_config3_driver_call_20_steps.json 2>/dev/null || echo "bench (20 steps) failed"
@@ -53,6 +53,7 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_fused $OUT/pmc_write_fused 134217728 fused:f64:1000000 $OUT/traffic.json fused > /dev/null
 fi
 if [ "$QUICK" != "quick" ]; then
+if [ "$QUICK" != "sweeps" ]; then          # (sweeps = the tables only: tools/collect_final_bench_lines.sh regenerates every bench line)
 echo "== other bench lines =="
 python3 $R/bench.py --no-cpu-baseline --mode fused > $OUT/bench_config3_fused.json 2>/dev/null
 python3 $R/bench.py --no-cpu-baseline --mode graph > $OUT/bench_config3_graph.json 2>/dev/null
@@ -65,6 +66,7 @@ python3 $R/bench.py --no-cpu-baseline --workload config5 --dtype f32 --steps 300
 python3 $R/bench.py --no-cpu-baseline --dtype f32 > $OUT/bench_config3_f32.json 2>/dev/null
 python3 $R/bench.py --no-cpu-baseline --dtype f32 --mode fused > $OUT/bench_config3_f32_fused.json 2>/dev/null
 python3 $R/bench.py --no-cpu-baseline --workload config5 --dtype f32 --mode fused --no-trajectory > $OUT/bench_config5_f32_fused_no_trajectory.json 2>/dev/null
+fi
 echo "== sweeps =="
 python3 $R/tools/sweep.py --members 100000,250000,500000,1000000,2000000,4000000 --modes per_step,fused 2>&1 | grep -v amdgpu.ids > $OUT/sweep_members.txt
 python3 $R/tools/sweep.py --members 8000000 --scenario-steps 330 --modes per_step,fused 2>&1 | grep -v amdgpu.ids >> $OUT/sweep_members.txt
@@ -73,5 +75,6 @@ python3 $R/tools/tiled_hist_bench.py --small 2>&1 | grep -v amdgpu.ids > $OUT/in
 python3 $R/tools/tiled_hist_bench.py --members 1000000 --dtype f64 2>&1 | grep -v amdgpu.ids > $OUT/in_loop_hist_1M_f64.txt
 python3 $R/tools/config5_demo.py 2>&1 | grep -v amdgpu.ids > $OUT/config5_shard_end_to_end.txt
 python3 $R/tools/packed_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/packed_ab.txt
+python3 $R/tools/summary_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/summary_timing.txt
 fi
 ls $OUT
