@@ -371,7 +371,10 @@ def main():
     # FIVEEQ_BENCH_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks
     # (ranks share devices, the summary exchange goes through host memory); the default is RCCL.
     backend = os.environ.get("FIVEEQ_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    # one rank per GPU; more ranks than GPUs share the devices round-robin — the gloo rehearsals on a one-GPU box do that on
+    # purpose, and under RCCL it is a misconfiguration that RCCL itself reports on first contact ("duplicate GPU"), i.e. inside
+    # the watchdog-protected summary section: the measurement survives (tested)
+    dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
     dist, data_group, tmo = None, None, None

@@ -164,6 +164,23 @@ def test_a_hung_summary_exchange_cannot_lose_the_measured_line():
     assert "timeout" in d["summary"]["error"] and d["value"] > 0 and d["n_gpus"] == 2 and d["roofline"]["frac"] > 0
 
 
+def test_an_rccl_failure_on_first_contact_costs_the_summary_not_the_measurement():
+    """Two ranks over RCCL on the ONE GPU of the test box: RCCL refuses two ranks on one device when its communicator comes up
+    — a real first-contact failure.  That happens in the summary section, after the measurement: rank 0 must still print the
+    complete line, with summary.error, and the job must exit non-zero."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box where two ranks must share one GPU")
+    out = _plain(2, *_SMALL, "--summary-watchdog-s", "25", env={"FIVEEQ_BENCH_BACKEND": "nccl"}, timeout=400)
+    assert out.returncode != 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert "error" in d["summary"] and d["value"] > 0 and d["n_gpus"] == 2 and d["config"]["collective_backend"] == "rccl"
+    assert d["config"]["control_plane"].startswith("gloo") and d["timing"]["host_share"] > 0
+    print("RCCL first-contact failure reported as:", d["summary"]["error"][:200])
+
+
 def test_four_ranks_enqueue_at_once_and_the_host_keeps_up():
     """The host side of north_star's >= 7x at 8 GPUs: every rank is one Python thread issuing 2 launches per 35 us (3.5 us of
     host time per hipLaunchKernel, profiles/r04/host_enqueue_profile.txt).  Four ranks of the driver's own workload — 1M
