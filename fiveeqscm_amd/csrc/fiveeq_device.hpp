@@ -1338,13 +1338,35 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
             mx = fmax(mx, v);
         }
     };
+    // the same value counted with a PLAIN LDS atomic: for rows that do not crowd into a few bins (see hist_bins_kernel: the
+    // crowding test of wave_lds_add runs once per group of four loads, on the first of them)
+    auto count_plain = [&](const T xv) {
+        const unsigned int b = hist_bin(rule, xv);
+        if (b != (unsigned int)BIN_NAN) atomicAdd(&h[b], 1u);
+        if constexpr (MOM) {
+            const double v = (double)xv;
+            s1 += v;
+            s2 = __builtin_fma(v, v, s2);
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+    };
     int64_t m = m0 + threadIdx.x;
     for (; m + 3 * FIVEEQ_BLOCK < m1; m += 4 * FIVEEQ_BLOCK) {      // four independent loads in flight per lane
         const T v0 = x[m], v1 = x[m + FIVEEQ_BLOCK], v2 = x[m + 2 * FIVEEQ_BLOCK], v3 = x[m + 3 * FIVEEQ_BLOCK];
-        count(v0);
-        count(v1);
-        count(v2);
-        count(v3);
+        const unsigned int b0 = hist_bin(rule, v0);
+        const unsigned int k0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)b0);
+        if (__popcll(__ballot(b0 == k0)) >= 16) {                    // wave-uniform: a crowded row
+            count(v0);
+            count(v1);
+            count(v2);
+            count(v3);
+        } else {
+            count_plain(v0);
+            count_plain(v1);
+            count_plain(v2);
+            count_plain(v3);
+        }
     }
     for (; m < m1; m += FIVEEQ_BLOCK) count(x[m]);
     if constexpr (MOM) {
@@ -1404,15 +1426,35 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_bins_kernel(const int64_t n
     const bool wide = ((((uintptr_t)x) | ((uintptr_t)(ld * 2))) & 15) == 0;
     int64_t m = m0 + (int64_t)threadIdx.x * 4;
     if (wide) {
+        // Eight members per lane.  The wave-level aggregation of wave_lds_add exists for rows whose members crowd into a
+        // handful of bins (the first decades of a run); it costs ~12 instructions per member, and beside a VALU-bound fused
+        // kernel this pass is paid in ISSUE SLOTS, not in bandwidth.  So the crowding test runs ONCE per load, on the lane's
+        // first member: a crowded row takes the aggregated path for all eight, every other row plain LDS atomics.
         auto count8 = [&](const uint4 v) {
-            count(v.x & 0xffffu);
-            count(v.x >> 16);
-            count(v.y & 0xffffu);
-            count(v.y >> 16);
-            count(v.z & 0xffffu);
-            count(v.z >> 16);
-            count(v.w & 0xffffu);
-            count(v.w >> 16);
+            const unsigned int b0 = v.x & 0xffffu;
+            const unsigned int k0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)b0);
+            if (__popcll(__ballot(b0 == k0)) >= 16) {                   // wave-uniform
+                count(b0);
+                count(v.x >> 16);
+                count(v.y & 0xffffu);
+                count(v.y >> 16);
+                count(v.z & 0xffffu);
+                count(v.z >> 16);
+                count(v.w & 0xffffu);
+                count(v.w >> 16);
+            } else {
+                auto plain = [&](const unsigned int b) {
+                    if (b < (unsigned int)n_bins) atomicAdd(&h[b], 1u);
+                };
+                plain(b0);
+                plain(v.x >> 16);
+                plain(v.y & 0xffffu);
+                plain(v.y >> 16);
+                plain(v.z & 0xffffu);
+                plain(v.z >> 16);
+                plain(v.w & 0xffffu);
+                plain(v.w >> 16);
+            }
         };
         constexpr int64_t STRIDE = 8 * FIVEEQ_BLOCK;
         const int64_t whole = m0 + (m1 - m0) / STRIDE * STRIDE;
