@@ -234,7 +234,7 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
     Returns [K, P] fp64 on rank `dst`, None elsewhere.  `stats`, if a dict, receives bytes_to_root / allreduce_bytes."""
     dist, rank, world, exchange = _dist(group)
     rows = rows.contiguous()
-    if rows.is_cuda and rows.dtype in (torch.float32, torch.float64) and len(percentiles) >= 1:
+    if _passes_apply(rows) and len(percentiles) >= 1:
         _, out = _device_summary(rows, percentiles, dst, group, stats, gmin=gmin, gmax=gmax, n_total=n_total,
                                  want_moments=False, n_bins=n_bins)
         return None if out is None else torch.from_numpy(out)
@@ -350,11 +350,23 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
 # The summary of DEVICE rows: HIP passes + host bookkeeping.
 # ---------------------------------------------------------------------------------------------------------------------
 def _lib_and_stream(rows):
+    """(library, _capi, ctypes, stream) for rows on a GPU.  (tests/test_distributed.py replaces this function to run the host
+    side of the summary on CPU tensors against the NumPy restatement of the passes, oracle/summary_passes.py.)"""
     import ctypes
 
     from . import _capi
     lib = _capi.load()
     return lib, _capi, ctypes, ctypes.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)
+
+
+def _passes_apply(rows):
+    """The summary of these rows goes through the four passes of the C ABI: fp32 / fp64 rows on a GPU."""
+    return rows.is_cuda and rows.dtype in (torch.float32, torch.float64)
+
+
+def _on(device):
+    import contextlib
+    return torch.cuda.device(device) if device.type == "cuda" else contextlib.nullcontext()
 
 
 def _all_reduce(dist, group, x, op):
@@ -372,7 +384,7 @@ def _all_gather_np(dist, group, world, arr):
     """every rank's NumPy array `arr` (same shape and dtype everywhere) -> array [world, ...], through the group's backend."""
     t = torch.from_numpy(np.ascontiguousarray(arr))
     if dist.get_backend(group) != "gloo":
-        t = t.cuda()
+        t = t.cuda()                                   # RCCL moves device tensors
     parts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(parts, t, group=group)
     return torch.stack(parts).cpu().numpy()
@@ -389,7 +401,7 @@ def device_row_sums(rows, out=None):
     if out is None:
         out = work[K * chunks * 4:].view(K, 4)
     fn = lib.fiveeq_row_moments_f64 if rows.dtype == torch.float64 else lib.fiveeq_row_moments_f32
-    with torch.cuda.device(rows.device):
+    with _on(rows.device):
         _capi.check(lib, fn(K, n, rows.stride(0), ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(work.data_ptr()),
                             ctypes.c_void_p(out.data_ptr()), st))
     return out
@@ -459,7 +471,7 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
         n_tot = n_local
 
     # ---- pass 2: histograms between the global extrema ------------------------------------------------------------------
-    with torch.cuda.device(dev):
+    with _on(dev):
         _capi.check(lib, getattr(lib, f"fiveeq_hist_rows_ranged_{sfx}")(K, n_local, ld, ptr(rows), ptr(ranges), n_bins,
                                                                         ptr(counts), st))
     if exchange:
@@ -512,7 +524,7 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
     pick = getattr(lib, f"fiveeq_select_pick_{sfx}")
     tail = torch.zeros(K + K * Q, dtype=torch.int64, device=dev)
     cand = torch.empty((K, cap), dtype=rows.dtype, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _capi.check(lib, select(K, n_local, ld, ptr(rows), ptr(ranges), n_bins, ptr(up, o_mask), ptr(cand), cap, ptr(tail), st))
         if not exchange:
             _capi.check(lib, pick(K, 1, cap, ptr(cand), ptr(tail), Q, ptr(up), ptr(tail, K * 8), st))
@@ -538,7 +550,7 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
             return mom, None
         pool = torch.stack(recv, dim=1).to(dev).contiguous()                           # [K, world, width]
         seg_n = torch.from_numpy(np.ascontiguousarray(all_n.T)).to(dev)                # [K, world]
-        with torch.cuda.device(dev):
+        with _on(dev):
             _capi.check(lib, pick(K, world, width, ptr(pool), ptr(seg_n), Q, ptr(up), ptr(tail, K * 8), st))
         tail_np = tail.cpu().numpy()
         tot_c = all_n.sum(axis=0)
@@ -570,7 +582,7 @@ def gather_summary(rows, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats
     engine's in-kernel records, EnsembleEngine.gather_summary."""
     dist, rank, world, exchange = _dist(group)
     rows = rows.contiguous()
-    if rows.is_cuda and rows.dtype in (torch.float32, torch.float64):
+    if _passes_apply(rows):
         mom_np, pct_np = _device_summary(rows, percentiles, dst, group, stats, local_sums=local_sums)
         mom = torch.from_numpy(mom_np)           # a few numbers per row: they stay on the host (HOST tensors for device rows)
         return {"count": mom[:, 0].clone(), "mean": mom[:, 1].clone(), "var": mom[:, 2] / mom[:, 0], "min": mom[:, 3].clone(),

@@ -273,3 +273,103 @@ def test_forced_collectives_in_a_one_rank_group():
         assert torch.equal(got_m[k], want_m[k])
         np.testing.assert_allclose(got[k].numpy(), want[k].numpy(), rtol=1e-12)
     assert torch.equal(got_h[0], want_h[0]) and torch.equal(got_h[1], want_h[1])
+
+
+# ---- the summary's PASS-BASED path (what device rows take: moments / ranged histogram / bin-mask selection / rank pick, host
+# bookkeeping in between) run on CPU tensors against the NumPy restatement of the four passes (oracle/summary_passes.py): the
+# container without a GPU still exercises which bins are marked, the rank arithmetic, the packed upload, and the multi-rank
+# exchange with one candidate segment per rank on the root -------------------------------------------------------------------
+def _use_oracle_passes():
+    import ctypes
+
+    from fiveeqscm_amd import distributed
+    from oracle.summary_passes import SummaryPasses
+
+    class _Check:
+        @staticmethod
+        def check(lib, rc):
+            assert rc == 0
+
+    passes = SummaryPasses()
+    distributed._lib_and_stream = lambda rows: (passes, _Check, ctypes, None)
+    distributed._passes_apply = lambda rows: rows.dtype in (torch.float32, torch.float64)
+
+
+def _worker_passes(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    _use_oracle_passes()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(4242)
+        full = np.stack([rng.normal(1.5, 0.7, size=n_total), rng.uniform(size=n_total) ** 3, np.full(n_total, 2.5),
+                         np.round(rng.normal(size=n_total), 1), rng.standard_cauchy(size=n_total)])
+        lo, hi = shard_bounds(n_total, rank, world)
+        pct = (0.0, 5.0, 49.9, 50.0, 50.0, 50.1, 95.0, 100.0)
+        ok = True
+        for dt in (np.float64, np.float32):
+            mine = torch.from_numpy(full[:, lo:hi].astype(dt))
+            st = {}
+            s = gather_summary(mine, percentiles=pct, stats=st)
+            if rank == 0:
+                x = full.astype(dt).astype(np.float64)
+                ok = ok and np.allclose(s["percentiles"].numpy(), np.percentile(x, pct, axis=1).T, rtol=1e-14, atol=0)
+                ok = ok and np.allclose(s["mean"].numpy(), x.mean(1), rtol=1e-12) and np.allclose(s["var"].numpy(), x.var(1), rtol=1e-9)
+                ok = ok and np.array_equal(s["min"].numpy(), x.min(1)) and np.array_equal(s["max"].numpy(), x.max(1))
+                ok = ok and s["count"].tolist() == [float(n_total)] * 5 and st["allreduce_bytes"] == 5 * 4096 * 8
+                ok = ok and (world == 1 or 0 < st["bytes_to_root"])
+            else:
+                ok = ok and s["percentiles"] is None and abs(float(s["mean"][0]) - full[0].astype(dt).astype(np.float64).mean()) < 1e-6
+        q.put(bool(ok))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 1001), (2, 4000), (8, 40_003)])
+def test_pass_based_summary_over_gloo_on_cpu(world, n_total):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_passes, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(results)
+
+
+def test_pass_based_summary_edge_cases_on_cpu(monkeypatch):
+    """One process, no group: ties, constant rows, heavy tails, a NaN row (-> NaN, like np.percentile), rows of 1, 2, 5
+    members, a ragged size — the selection logic of the device path, on the NumPy restatement of its passes."""
+    from fiveeqscm_amd import distributed
+    from fiveeqscm_amd.distributed import exact_percentiles
+    saved = distributed._lib_and_stream, distributed._passes_apply
+    try:
+        _use_oracle_passes()
+        rng = np.random.default_rng(9)
+        pct = (0.0, 5.0, 33.3, 49.999, 50.0, 50.001, 95.0, 100.0)
+        for n in (1, 2, 5, 64, 1000, 70_001):
+            x = np.stack([rng.normal(1.8, 0.6, size=n), rng.uniform(size=n) ** 3, np.full(n, 2.5), np.round(rng.normal(size=n), 1),
+                          rng.standard_cauchy(size=n), np.where(rng.uniform(size=n) < 0.9, 0.25, rng.normal(size=n))])
+            for dt in (np.float64, np.float32):
+                xs = x.astype(dt)
+                out = gather_summary(torch.from_numpy(xs), pct)
+                x64 = xs.astype(np.float64)
+                want = np.percentile(x64, pct, axis=1).T
+                np.testing.assert_allclose(out["percentiles"].numpy(), want, rtol=1e-14, atol=0, err_msg=f"n={n} {dt}")
+                np.testing.assert_allclose(out["mean"].numpy(), x64.mean(1), rtol=1e-12, atol=1e-13)
+                sel = exact_percentiles(torch.from_numpy(xs), pct, torch.from_numpy(x64.min(1)), torch.from_numpy(x64.max(1)), n)
+                np.testing.assert_allclose(sel.numpy(), want, rtol=1e-14, atol=0)
+        y = rng.normal(size=(2, 5000))
+        y[1, 77] = np.nan
+        out = gather_summary(torch.from_numpy(y), (5.0, 50.0, 95.0))
+        np.testing.assert_allclose(out["percentiles"].numpy()[0], np.percentile(y[0], (5.0, 50.0, 95.0)), rtol=1e-14)
+        assert np.isnan(out["percentiles"].numpy()[1]).all() and np.isnan(out["mean"][1].item())
+        assert out["min"][1].item() == np.nanmin(y[1]) and out["max"][1].item() == np.nanmax(y[1])
+    finally:
+        distributed._lib_and_stream, distributed._passes_apply = saved
