@@ -28,6 +28,9 @@ the fused / K-step kernels with their own A and bound "fp64-valu".  `cpu_baselin
 (NumPy, one process per usable core, and the plain-C port under OpenMP) on this box's host cores on a bounded sample
 (rank 0, N=1 only) BEFORE the GPU is touched, so that the GPU work of the run is one contiguous window.
 
+With N > 1 and no explicit --mode the per-step form falls back to its hipGraph replay (same kernels, same bits) when the slowest
+rank's host thread needs more than --host-share-limit (0.5) of a step to enqueue it: `config.mode`, `timing.host_fallback`.
+
 N > 1: one process per GPU; time-stepping needs no collective.  The barriers around the clocked region and the MAX of the
 clocked times go over a gloo control group (host scalars); the end-of-run summary exchange — the only collective that moves
 ensemble data — goes over RCCL, LAST, with the line already complete and a watchdog thread beside it: a failed or hung
@@ -149,7 +152,10 @@ def parse():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--members", type=int, default=0, help="members per GPU (default: the workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--mode", default="per_step", choices=["per_step", "graph", "fused", "ksteps", "auto", "tiled"])
+    ap.add_argument("--mode", default=None, choices=["per_step", "graph", "fused", "ksteps", "auto", "tiled"],
+                    help="default: per_step — and, for N > 1 only, its hipGraph replay (same kernels, same bits) if the host "
+                         "thread of the slowest rank needs more than --host-share-limit of a step to enqueue it")
+    ap.add_argument("--host-share-limit", type=float, default=0.5)
     ap.add_argument("--k-steps", type=int, default=0, help="steps per launch for --mode ksteps/tiled (0: the engine's choice)")
     ap.add_argument("--no-trajectory", action="store_true", help="do not store C/T rows (drops G+1 writes from A)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -453,7 +459,7 @@ def main():
     # clocked, and the MEDIAN block is what `value` and `ms_per_step` report: a 20-step call is not one sub-millisecond
     # sample, and the card is visibly busy for seconds to anything that samples it from outside.  `timed_repeats` says how
     # many blocks were clocked and `first_block_ms_per_step` keeps the single-sample figure.
-    t_idx = run_steps(eng, 0, a.warmup, a.mode, k_steps)
+    t_idx = run_steps(eng, 0, a.warmup, a.mode or "per_step", k_steps)
 
     def prepare_graphs(t_from, k):
         while k > 0:
@@ -465,6 +471,50 @@ def main():
     fail_rank = os.environ.get("FIVEEQ_BENCH_FAIL_RANK")        # test hook: this rank dies before the timed region
     if fail_rank is not None and int(fail_rank) == rank:
         os._exit(17)
+
+    # ---- the HOST side of a step: how long this rank's CPU thread needs to ENQUEUE one timestep (Python + ctypes + the
+    # hipLaunchKernel calls inside fiveeq_run_*), measured on a drained device with a short burst so that the HIP queue never
+    # fills (a full queue blocks the caller: that would clock the device, not the host).  Every sample starts behind a
+    # barrier, so with N ranks all N host threads enqueue AT THE SAME TIME — the contention an 8-GPU node's host side sees.
+    # host_share = enqueue time / step time: the fraction of a step the host thread is busy; < 1 means the device, not the
+    # host, paces the run (north_star's >= 7x at 8 GPUs needs this to stay well below 1 with 8 ranks enqueuing at once).
+    k_burst = max(1, min(a.steps, 40))
+
+    def host_enqueue(mode, t_from):
+        """(median, min) seconds per step over 15 bursts, MAX over ranks; the device time per step of the same bursts
+        (HIP events, MAX over ranks, median); the next scenario index."""
+        enq, dev_t = [], []
+        for _ in range(15):
+            if mode == "graph":
+                prepare_graphs(t_from % n_scen, k_burst)
+            sync_all()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            t0 = time.perf_counter()
+            t_from = run_steps(eng, t_from, k_burst, mode, k_steps, join=False)
+            enq.append((time.perf_counter() - t0) / k_burst)
+            eng.join()
+            e1.record()
+            e1.synchronize()
+            dev_t.append(e0.elapsed_time(e1) * 1e-3 / k_burst)
+        torch.cuda.synchronize(dev)
+        med, mn, dmed = max_over_ranks([float(np.median(enq)), float(np.min(enq)), float(np.median(dev_t))])
+        return med, mn, dmed, t_from
+
+    # Which launch form the timed region uses.  An explicit --mode is taken as given.  The default is the per-step form —
+    # and, for N > 1 only, its hipGraph replay when the slowest rank's host thread needs more than --host-share-limit of a
+    # step to enqueue it with all ranks enqueuing at once (same kernels in the same layout, bit-identical results; 1/4 of the
+    # host time): a host-bound node must not pass for a slow GPU.  `config.mode` says what ran, `timing.host_*` why.
+    mode_requested = a.mode
+    fallback = None
+    if a.mode is None:
+        a.mode = "per_step"
+        if world > 1 or os.environ.get("FIVEEQ_BENCH_FORCE_HOST_CHECK") == "1":
+            e_med, _, d_med, t_idx = host_enqueue("per_step", t_idx)
+            fallback = {"per_step_host_enqueue_us_per_step": e_med * 1e6, "per_step_burst_us_per_step": d_med * 1e6,
+                        "per_step_host_share": e_med / d_med, "limit": a.host_share_limit, "switched_to_graph": False}
+            if e_med / d_med >= a.host_share_limit:
+                a.mode, fallback["switched_to_graph"] = "graph", True
 
     def timed_block(t_from):
         """One K-step block on the wall clock: barrier, device sync, clock, K steps, drained stream, clock.  Also returns
@@ -538,24 +588,7 @@ def main():
     elapsed = float(np.median(blocks))
     value = n_total * a.steps / elapsed
 
-    # ---- the HOST side of a step: how long this rank's CPU thread needs to ENQUEUE one timestep (Python + ctypes + the
-    # hipLaunchKernel calls inside fiveeq_run_*), measured on a drained device with a short burst so that the HIP queue never
-    # fills (a full queue blocks the caller: that would clock the device, not the host).  Every sample starts behind a
-    # barrier, so with N ranks all N host threads enqueue AT THE SAME TIME — the contention an 8-GPU node's host side sees.
-    # host_share = enqueue time / step time: the fraction of a step the host thread is busy; < 1 means the device, not the
-    # host, paces the run (north_star's >= 7x at 8 GPUs needs this to stay well below 1 with 8 ranks enqueuing at once).
-    k_burst = max(1, min(a.steps, 40))
-    enq = []
-    for _ in range(15):
-        if a.mode == "graph":
-            prepare_graphs(t_idx % n_scen, k_burst)
-        sync_all()
-        t0 = time.perf_counter()
-        t_idx = run_steps(eng, t_idx, k_burst, a.mode, k_steps, join=False)
-        enq.append((time.perf_counter() - t0) / k_burst)
-        eng.join()
-    torch.cuda.synchronize(dev)
-    enq_med, enq_min = max_over_ranks([float(np.median(enq)), float(np.min(enq))])
+    enq_med, enq_min, _, t_idx = host_enqueue(a.mode, t_idx)
     timing = {"timed_repeats": repeats, "block_ms_min_median_max": [min(blocks) * 1e3, elapsed * 1e3, max(blocks) * 1e3],
               "device_s_clocked": float(np.sum(blocks)),
               "first_block_ms_per_step": first_max / a.steps * 1e3,
@@ -565,6 +598,7 @@ def main():
               max_over_ranks([wall_all])[0] / (a.steps * repeats) * 1e3,
               "host_enqueue_us_per_step": enq_med * 1e6, "host_enqueue_us_per_step_min": enq_min * 1e6,
               "host_share": enq_med / (elapsed / a.steps),
+              "host_fallback": fallback,
               "host_enqueue_is": (f"median (and min) over 15 bursts of {k_burst} steps of the wall time this rank's thread spends "
                                   "inside engine.run -> fiveeq_run_* (enqueue only, drained device, queue never full), every "
                                   f"burst behind a barrier so that all {world} rank(s) enqueue at once; MAX over ranks; "
@@ -779,6 +813,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{a.workload}: {desc}", "members_per_gpu": per_gpu, "members_total": n_total,
                    "gases": G, "pools": eng.pools, "scenario_steps": n_scen, "mode": a.mode,
+                   "mode_requested": mode_requested or "default",
                    "steps_per_launch": (roofline.get("steps_per_launch", 1)),
                    "trajectory_stored": eng.C is not None, "parallelism": f"member-shard x{world}",
                    "chunk_members": eng.chunk_members,

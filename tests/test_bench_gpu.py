@@ -181,6 +181,25 @@ def test_an_rccl_failure_on_first_contact_costs_the_summary_not_the_measurement(
     print("RCCL first-contact failure reported as:", d["summary"]["error"][:200])
 
 
+def test_a_host_bound_multi_rank_run_falls_back_to_graph_replay():
+    """N > 1, no explicit --mode: if the slowest rank's host thread needs more than --host-share-limit of a step to enqueue
+    it, the timed region runs the hipGraph replay of the same launches (same kernels, same bits).  Forced here with a limit
+    of 0; the default limit leaves the per-step form in place; an explicit --mode is never overridden."""
+    forced = _one_line(_plain(2, *_SMALL, "--host-share-limit", "0"))
+    assert forced["config"]["mode"] == "graph" and forced["config"]["mode_requested"] == "default"
+    fb = forced["timing"]["host_fallback"]
+    assert fb["switched_to_graph"] is True and fb["per_step_host_share"] > 0 and fb["limit"] == 0.0
+    kept = _one_line(_plain(2, *_SMALL))
+    assert kept["config"]["mode"] == "per_step" and kept["timing"]["host_fallback"]["switched_to_graph"] is False
+    assert kept["timing"]["host_fallback"]["per_step_host_share"] < 0.5
+    _summaries_agree(forced["summary"], kept["summary"], rel=0.0)                  # bit-identical kernels
+    assert forced["timing"]["host_enqueue_us_per_step"] < kept["timing"]["host_enqueue_us_per_step"]
+    explicit = _one_line(_plain(2, *_SMALL, "--mode", "per_step", "--host-share-limit", "0"))
+    assert explicit["config"]["mode"] == "per_step" and explicit["timing"]["host_fallback"] is None
+    one = _bench(*_SMALL)
+    assert one["config"]["mode"] == "per_step" and one["config"]["mode_requested"] == "default" and one["timing"]["host_fallback"] is None
+
+
 def test_four_ranks_enqueue_at_once_and_the_host_keeps_up():
     """The host side of north_star's >= 7x at 8 GPUs: every rank is one Python thread issuing 2 launches per 35 us (3.5 us of
     host time per hipLaunchKernel, profiles/r04/host_enqueue_profile.txt).  Four ranks of the driver's own workload — 1M
