@@ -218,6 +218,7 @@ def _round_up_to(dtype, t):
 
 
 SELECT_CHUNK_ELEMS = 1 << 25     # elements of `rows` compared at a time in exact_percentiles (x P boolean temporaries)
+SELECT_CAND_BYTES = 4 << 30      # device summary: rows are summarised in halves while rows x candidates-per-row exceeds this
 
 
 def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None, n_bins=SELECT_BINS, stats=None):
@@ -509,6 +510,14 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
     ranks = cand_below[rk, bb] + (want[None, :] - below_bin[rk, bb])                    # [K, 2P]
     ranks[skip] = -1
     n_cand = (counts_np * marked).sum(axis=1)                                            # candidates per row over ALL ranks
+    if K > 1 and K * int(n_cand.max()) * w > SELECT_CAND_BYTES:
+        # one row with heavy ties would size the candidate buffer of EVERY row: summarise the rows in two halves (the decision
+        # rests on the all-reduced histogram, so every rank takes it alike); the extrema and the member count are known
+        h = K // 2
+        halves = [_device_summary(rows[a:b], percentiles, dst, group, None, gmin=lo_np[a:b], gmax=hi_np[a:b], n_total=n_tot,
+                                  want_moments=False, n_bins=n_bins)[1] for a, b in ((0, h), (h, K))]
+        out = None if halves[0] is None else np.concatenate(halves, axis=0)
+        return mom, out
     cap = max(1, int(min(n_local, n_cand.max())))
     words = (n_bins + 31) // 32
     bits = np.zeros((K, words * 32), dtype=np.uint8)

@@ -365,6 +365,16 @@ def test_pass_based_summary_edge_cases_on_cpu(monkeypatch):
                 np.testing.assert_allclose(out["mean"].numpy(), x64.mean(1), rtol=1e-12, atol=1e-13)
                 sel = exact_percentiles(torch.from_numpy(xs), pct, torch.from_numpy(x64.min(1)), torch.from_numpy(x64.max(1)), n)
                 np.testing.assert_allclose(sel.numpy(), want, rtol=1e-14, atol=0)
+        # a row of heavy ties beside ordinary rows: past SELECT_CAND_BYTES the rows are summarised in halves, recursively
+        monkeypatch.setattr(distributed, "SELECT_CAND_BYTES", 20_000)
+        z = rng.normal(size=(7, 3000))
+        z[2] = np.where(rng.uniform(size=3000) < 0.95, 1.25, z[2])
+        z[5, 11] = np.nan
+        got = gather_summary(torch.from_numpy(z), (5.0, 50.0, 95.0))["percentiles"].numpy()
+        ok_rows = [0, 1, 2, 3, 4, 6]
+        np.testing.assert_allclose(got[ok_rows], np.percentile(z[ok_rows], (5.0, 50.0, 95.0), axis=1).T, rtol=1e-14, atol=0)
+        assert np.isnan(got[5]).all()
+        monkeypatch.setattr(distributed, "SELECT_CAND_BYTES", 4 << 30)
         y = rng.normal(size=(2, 5000))
         y[1, 77] = np.nan
         out = gather_summary(torch.from_numpy(y), (5.0, 50.0, 95.0))

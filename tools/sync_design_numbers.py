@@ -14,7 +14,7 @@ path = os.path.join(ROOT, "DESIGN.md")
 text = open(path).read()
 cache, out, last, changed = {}, [], 0, 0
 for m in t.CITE.finditer(text):
-    f = t._resolve(m["file"])
+    f = t._resolve(m["file"], t.DOCS["DESIGN.md"])
     if f not in cache:
         cache[f] = json.load(open(f))
     val = t._lookup(cache[f], m["key"], m["path"])
