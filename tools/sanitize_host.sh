@@ -7,7 +7,9 @@ set -eu
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/libfiveeq_hip_asan.so
 RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.asan-x86_64.so" | head -1)
+HASH=$(cat "$R/fiveeqscm_amd/csrc/fiveeq_capi.hip" "$R/fiveeqscm_amd/csrc/fiveeq_device.hpp" "$R/include/fiveeq.h" | sha256sum | cut -c1-64)
 /opt/rocm/bin/hipcc -O1 -g -std=c++17 -ffp-contract=off -fPIC -shared --offload-arch=gfx950 -I "$R/include" \
+    -DFIVEEQ_SOURCE_HASH="\"$HASH\"" \
     -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-gpu-sanitize -shared-libsan \
     -o "$OUT" "$R/fiveeqscm_amd/csrc/fiveeq_capi.hip"
 cd "$R"
