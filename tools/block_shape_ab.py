@@ -2,7 +2,7 @@
 """A/B of workgroup shapes (builds with -DFIVEEQ_BLOCK=... / -DFIVEEQ_TILE_BLOCK=..., see tools/variant_ab.py): is the cost of
 the time-tiled kernel's shape its 1024-thread workgroup?  fp32, config-5 shard, statistics on, nothing stored.
 
-    python3 tools/block_shape_ab.py default build_variants/libfiveeq_B1024.so ...
+    python3 tools/block_shape_ab.py default /tmp/fiveeq_variants/libfiveeq_B1024.so ...
 """
 import os
 import sys

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Experiment (needs a build with -DFIVEEQ_FUSED_TIMING): when and on which CU does every wave of ONE launch of the fused
 packed-fp32 kernel run?  Prints the number of waves resident per CU over time and wave lifetimes by start order.
-    python3 tools/fused_timing.py build_variants/libfiveeq_FT.so [workgroups_per_cu ...]"""
+    python3 tools/fused_timing.py /tmp/fiveeq_variants/libfiveeq_FT.so [workgroups_per_cu ...]"""
 import collections
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B: what the time-tiled kernel's shape costs against the fused kernel.  Variant libraries are built with
-`make -C fiveeqscm_amd/csrc OUT=../../build_variants/<name>.so EXTRA=-D...` (see profiles/r02/ab_variants.txt)."""
+`make -C fiveeqscm_amd/csrc OUT=/tmp/fiveeq_variants/<name>.so EXTRA=-D...` (see profiles/r02/ab_variants.txt)."""
 import os
 import sys
 import time
@@ -32,9 +32,9 @@ def timed(eng, **kw):
     return best / steps * 1e6
 
 
-VARIANTS = os.path.join(ROOT, "build_variants")
+VARIANTS = "/tmp/fiveeq_variants"        # built on the GPU box: make -C fiveeqscm_amd/csrc OUT=... EXTRA=-D...
 for name in [None] + (sorted(os.listdir(VARIANTS)) if os.path.isdir(VARIANTS) else []):
-    path = None if name is None else os.path.join(ROOT, "build_variants", name)
+    path = None if name is None else os.path.join(VARIANTS, name)
     if name is not None and not name.endswith(".so"):
         continue
     for stats in (True, False):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-step kernel timing across builds of the library (occupancy variants etc.): us per step, best of 3 passes.
-    python3 tools/step_variant_ab.py default build_variants/libfiveeq_X.so ..."""
+    python3 tools/step_variant_ab.py default /tmp/fiveeq_variants/libfiveeq_X.so ..."""
 import os
 import sys
 import time

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from fiveeqscm_amd import emissions, params  # noqa: E402
 from fiveeqscm_amd.engine import EnsembleEngine  # noqa: E402
 
-LIB = os.environ.get("FIVEEQ_VARIANT_LIB") or None       # e.g. build_variants/lib_nt_store.so
+LIB = os.environ.get("FIVEEQ_VARIANT_LIB") or None       # e.g. /tmp/fiveeq_variants/lib_nt_store.so
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 12_500_000
 dt = torch.float32 if (len(sys.argv) < 3 or sys.argv[2] == "f32") else torch.float64
 steps = 128

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment (needs a build with -DFIVEEQ_TILE_TIMING): start / end time and placement of every persistent workgroup of ONE
-launch of the time-tiled kernel.    python3 tools/tile_timing.py build_variants/libfiveeq_TT.so [members] [K]"""
+launch of the time-tiled kernel.    python3 tools/tile_timing.py /tmp/fiveeq_variants/libfiveeq_TT.so [members] [K]"""
 import collections
 import os
 import sys

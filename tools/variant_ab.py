@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of builds of the library (tools: make OUT=build_variants/libfiveeq_X.so EXTRA=-D...): fused fp32 kernel at the
+"""A/B of builds of the library (tools: make OUT=/tmp/fiveeq_variants/libfiveeq_X.so EXTRA=-D...): fused fp32 kernel at the
 config-5 shard (us/step), ulp of the fp32 exp / expm1 primitives, and fp32-vs-fp64 trajectory differences.
     python3 tools/variant_ab.py lib1.so [lib2.so ...]        ("default" = the in-tree build)"""
 import ctypes
