@@ -156,3 +156,70 @@ def test_engine_summary_takes_its_moments_from_the_kernel_records():
     np.testing.assert_allclose(sa["mean"].cpu().numpy(), T.mean(1), rtol=1e-13)
     with pytest.raises(ValueError, match="not stored"):
         a.gather_summary([3])
+
+
+def test_hip_passes_against_their_numpy_restatement():
+    """oracle/summary_passes.py restates the four passes in NumPy behind the C ABI's signatures (it stands in for the library
+    in the CPU tests of the multi-rank exchange).  Here the two meet on the same rows: moments, histogram counts, candidate
+    sets and picked order statistics of the HIP kernels against the restatement — fp64 exactly; fp32 up to the restatement's
+    double rounding of the fp32 FMA (a member within 2^-24 of a bin edge may sit in the neighbouring bin)."""
+    from fiveeqscm_amd import _capi
+    from oracle.summary_passes import SummaryPasses
+    lib, cpu = _capi.load(), SummaryPasses()
+    rng = np.random.default_rng(12)
+    n, nb, K = 200_003, 4096, 3
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    for np_dt, sfx in ((np.float64, "f64"), (np.float32, "f32")):
+        x = (rng.normal(1.8, 0.6, size=(K, n)) * np.array([[1.0], [0.3], [2.5]])).astype(np_dt)
+        x[2, 100] = np.nan
+        rows_d, rows_h = torch.from_numpy(x).cuda(), torch.from_numpy(x.copy())
+        ranges = np.stack([np.nanmin(x, axis=1), np.nanmax(x, axis=1)], axis=1).astype(np.float64)
+        rg_d, rg_h = torch.from_numpy(ranges).cuda(), torch.from_numpy(ranges.copy())
+        # moments
+        chunks = int(lib.fiveeq_row_moments_chunks(K, n))
+        part = torch.empty(K * chunks * 4, dtype=torch.float64, device="cuda")
+        mom_d, mom_h = torch.empty((K, 4), dtype=torch.float64, device="cuda"), torch.empty((K, 4), dtype=torch.float64)
+        _capi.check(lib, getattr(lib, f"fiveeq_row_moments_{sfx}")(K, n, n, p(rows_d), p(part), p(mom_d), None))
+        assert getattr(cpu, f"fiveeq_row_moments_{sfx}")(K, n, n, p(rows_h), None, p(mom_h), None) == 0
+        a, b = mom_d.cpu().numpy(), mom_h.numpy()
+        np.testing.assert_allclose(a[:2, :2], b[:2, :2], rtol=1e-12)
+        assert np.array_equal(a[:, 2:], b[:, 2:]) and np.isnan(a[2, 0]) and np.isnan(b[2, 0])
+        # histogram
+        h_d, h_h = torch.zeros((K, nb), dtype=torch.int64, device="cuda"), torch.zeros((K, nb), dtype=torch.int64)
+        _capi.check(lib, getattr(lib, f"fiveeq_hist_rows_ranged_{sfx}")(K, n, n, p(rows_d), p(rg_d), nb, p(h_d), None))
+        assert getattr(cpu, f"fiveeq_hist_rows_ranged_{sfx}")(K, n, n, p(rows_h), p(rg_h), nb, p(h_h), None) == 0
+        hd, hh = h_d.cpu().numpy(), h_h.numpy()
+        assert hd.sum(1).tolist() == hh.sum(1).tolist() == [n, n, n - 1]
+        moved = np.abs(hd - hh).sum(1) // 2
+        assert (moved == 0).all() if sfx == "f64" else (moved <= 2).all(), moved
+        # selection + pick on the bins that hold p05 / p50 / p95 of the device's own histogram
+        cdf = np.cumsum(hd, axis=1)
+        want = (np.array([0.05, 0.5, 0.95])[None, :] * (cdf[:, -1:] - 1)).astype(np.int64)
+        bb = np.stack([np.searchsorted(cdf[k], want[k], side="right") for k in range(K)])
+        marked = np.zeros((K, nb), dtype=bool)
+        marked[np.arange(K)[:, None], bb] = True
+        words = nb // 32
+        mask = np.packbits(marked.reshape(K, words, 32), axis=2, bitorder="little").view(np.uint32).reshape(K, words)
+        cap = int((hd * marked).sum(1).max()) + 8
+        out = {}
+        for name, L, rows_t, rg_t, dev in (("hip", lib, rows_d, rg_d, "cuda"), ("numpy", cpu, rows_h, rg_h, "cpu")):
+            m_t = torch.from_numpy(mask.view(np.int32).copy()).to(dev)
+            cand = torch.zeros((K, cap), dtype=rows_t.dtype, device=dev)
+            cn = torch.zeros(K, dtype=torch.int64, device=dev)
+            assert getattr(L, f"fiveeq_select_bins_{sfx}")(K, n, n, p(rows_t), p(rg_t), nb, p(m_t), p(cand), cap, p(cn), None) == 0
+            below = np.concatenate([np.zeros((K, 1), dtype=np.int64), cdf[:, :-1]], axis=1)
+            cb = np.concatenate([np.zeros((K, 1), dtype=np.int64), np.cumsum(hd * marked, axis=1)[:, :-1]], axis=1)
+            ranks = torch.from_numpy(np.ascontiguousarray(np.take_along_axis(cb, bb, 1) + want - np.take_along_axis(below, bb, 1))).to(dev)
+            picked = torch.zeros((K, 3), dtype=torch.float64, device=dev)
+            assert getattr(L, f"fiveeq_select_pick_{sfx}")(K, 1, cap, p(cand), p(cn), 3, p(ranks), p(picked), None) == 0
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            out[name] = (cn.cpu().numpy(), [np.sort(cand[k, :int(cn[k])].cpu().numpy()) for k in range(K)], picked.cpu().numpy())
+        if sfx == "f64":
+            assert np.array_equal(out["hip"][0], out["numpy"][0]) and np.array_equal(out["hip"][2], out["numpy"][2])
+            assert all(np.array_equal(a_, b_) for a_, b_ in zip(out["hip"][1], out["numpy"][1]))
+        assert np.array_equal(out["hip"][0], (hd * marked).sum(1))                 # the kernels agree with their own histogram
+        x64 = x.astype(np.float64)
+        for k in range(K):                                                          # ... and the picks are np.sort's order statistics
+            srt = np.sort(x64[k][~np.isnan(x64[k])])
+            assert np.array_equal(out["hip"][2][k], srt[want[k]])
