@@ -835,7 +835,15 @@ int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, d
     if (n_rows == 0) return FIVEEQ_OK;
     if (!rows || !hist) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
     if (n_rows > 65535) return fail(FIVEEQ_E_INVALID, "n_rows=%d exceeds the 65535 rows of one launch", n_rows);
-    const int64_t chunk = hist_chunk(n_rows, n);
+    int64_t chunk = hist_chunk(n_rows, n);
+    if (ranges) {
+        // the summary's histogram (a few rows): every workgroup zeroes and flushes all n_bins counters, which at 2048 workgroups
+        // of 18k members each is a third of the pass (68 us for 3 x 12.5M fp32 values at 4096 bins, 40 at 1024 bins) — at least
+        // 8 members per bin and workgroup: 47 us.  (The ring passes count 64+ rows per launch and are far beyond that already;
+        // the entry points with moments keep the chunking fiveeq_hist_rows_chunks advertises.)
+        const int64_t floor_ = (8LL * n_bins + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK * FIVEEQ_BLOCK;
+        if (chunk < floor_) chunk = floor_;
+    }
     const int64_t chunks = (n + chunk - 1) / chunk;
     if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
     const double inv_w = ranges ? 0.0 : (double)n_bins / (hi - lo);
