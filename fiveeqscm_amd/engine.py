@@ -899,7 +899,7 @@ class EnsembleEngine:
             raise ValueError(f"steps {missing} are not stored (out_steps)")
         rows = self.T[[row_of[int(t)] for t in steps]]
         sums = None
-        if self.collect_stats:
+        if self.collect_stats and all(self._stats_have[int(t)] for t in steps):       # else: the moments pass over the rows
             sums = torch.cat([self.stats_sums(int(t), int(t) + 1) for t in steps])[:, 1:5].contiguous()
         return gather_summary(rows, percentiles, dst=dst, group=group, stats=stats, local_sums=sums)
 

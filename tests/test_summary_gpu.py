@@ -156,6 +156,14 @@ def test_engine_summary_takes_its_moments_from_the_kernel_records():
     np.testing.assert_allclose(sa["mean"].cpu().numpy(), T.mean(1), rtol=1e-13)
     with pytest.raises(ValueError, match="not stored"):
         a.gather_summary([3])
+    # an engine that holds no moments for a step (a state-only checkpoint loaded, the step's row restored by hand) falls back
+    # to the moments pass instead of reading zero-filled records
+    c = EnsembleEngine(p, N, E, device="cuda:0", output_steps=steps, store_concentrations=False, collect_stats=True)
+    c.load_state_dict(a.state_dict(include_outputs=False))
+    c.T.copy_(a.T)
+    assert not c._stats_have.any()
+    sc = c.gather_summary(steps)
+    assert torch.equal(sc["percentiles"], sb["percentiles"]) and torch.allclose(sc["mean"], sb["mean"], rtol=1e-13)
 
 
 def test_hip_passes_against_their_numpy_restatement():
