@@ -381,11 +381,12 @@ def _all_reduce(dist, group, x, op):
     return x
 
 
-def _all_gather_np(dist, group, world, arr):
-    """every rank's NumPy array `arr` (same shape and dtype everywhere) -> array [world, ...], through the group's backend."""
+def _all_gather_np(dist, group, world, arr, device):
+    """every rank's NumPy array `arr` (same shape and dtype everywhere) -> array [world, ...], through the group's backend
+    (RCCL moves device tensors: they go through `device`, the rank's GPU)."""
     t = torch.from_numpy(np.ascontiguousarray(arr))
     if dist.get_backend(group) != "gloo":
-        t = t.cuda()                                   # RCCL moves device tensors
+        t = t.to(device)
     parts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(parts, t, group=group)
     return torch.stack(parts).cpu().numpy()
@@ -455,7 +456,7 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
     if exchange or gmin is not None:
         if have_sums:
             mine = np.concatenate([np.full((K, 1), float(n_local)), sums_dev.cpu().numpy()], axis=1)      # [K, 5]
-            parts = _all_gather_np(dist, group, world, mine) if exchange else mine[None]
+            parts = _all_gather_np(dist, group, world, mine, dev) if exchange else mine[None]
             cnt, s1 = parts[:, :, 0], parts[:, :, 1]
             mean_r = s1 / cnt
             m2_r = np.maximum(parts[:, :, 2] - cnt * mean_r * mean_r, 0.0)
@@ -543,7 +544,7 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
     if exchange:
         # several ranks: the candidates travel to the root (a few thousand values out of the ensemble) and the root's pick
         # pass runs over one segment per rank
-        all_n = _all_gather_np(dist, group, world, cand_n)                             # [world, K]
+        all_n = _all_gather_np(dist, group, world, cand_n, dev)                             # [world, K]
         width = max(int(all_n.max()), 1)
         send = cand[:, :min(width, cap)]
         if send.shape[1] < width:
