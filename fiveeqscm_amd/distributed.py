@@ -177,28 +177,11 @@ SELECT_BINS = 4096
 
 
 def _row_histograms(rows, lo, hi, n_bins):
-    """counts [K, n_bins] int64 of rows [K, n] between per-row lo/hi (lists of floats).  On the GPU the engine's
-    LDS-privatised histogram kernel (fiveeq_hist_rows_*, ~10 us per 12.5M-member row); elsewhere torch.  The caller
-    never relies on the exact bin of a value (candidates are re-selected by VALUE with a one-bin margin), so the two
-    back ends need not agree at bin edges."""
+    """counts [K, n_bins] int64 of HOST rows [K, n] between per-row lo/hi (lists of floats), in torch ops.  (Rows on a GPU
+    never come here: their summary runs through the HIP passes, _device_summary.)  The caller never relies on the exact bin
+    of a value — candidates are re-selected by VALUE with a one-bin margin."""
     K, n = rows.shape
     counts = torch.zeros((K, n_bins), dtype=torch.int64, device=rows.device)
-    if rows.is_cuda and rows.dtype in (torch.float32, torch.float64):
-        import ctypes
-
-        from . import _capi
-        lib = _capi.load()
-        fn = lib.fiveeq_hist_rows_f64 if rows.dtype == torch.float64 else lib.fiveeq_hist_rows_f32
-        w = rows.element_size()
-        with torch.cuda.device(rows.device):
-            st = ctypes.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)
-            for k in range(K):
-                if hi[k] > lo[k]:
-                    _capi.check(lib, fn(1, n, n, ctypes.c_void_p(rows.data_ptr() + k * n * w), lo[k], hi[k], n_bins,
-                                        ctypes.c_void_p(counts.data_ptr() + k * n_bins * 8), st))
-                else:
-                    counts[k, 0] = n
-        return counts
     for k in range(K):
         if hi[k] > lo[k]:
             idx = ((rows[k].to(torch.float64) - lo[k]) * (n_bins / (hi[k] - lo[k]))).floor_().clamp_(0, n_bins - 1)
