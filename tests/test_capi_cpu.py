@@ -295,3 +295,18 @@ def test_engine_module_validates_its_environment():
             engine._env_choice("FIVEEQ_HIST_PASS_STREAM", "side", ("side", "same"))
         finally:
             del os.environ["FIVEEQ_HIST_PASS_STREAM"]
+
+
+def test_the_ctypes_stub_in_integration_md_binds_the_built_library():
+    """INTEGRATION.md shows the binding a maintainer of the reference would add.  Execute that very code block against the
+    built library: its struct mirror, ABI number and argument list must be the library's (the document cannot drift)."""
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as fh:
+        text = fh.read()
+    block = re.search(r"```python\n(# U_FaIR/_fiveeq_hip\.py.*?)```", text, re.S).group(1)
+    assert 'ctypes.CDLL("libfiveeq_hip.so")' in block
+    code = block.replace('ctypes.CDLL("libfiveeq_hip.so")', f"ctypes.CDLL({_capi.LIB_PATH!r})")
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)                  # its own asserts: ABI version, sizeof(model), build flags
+    assert ctypes.sizeof(ns["Model"]) == ctypes.sizeof(_capi.Model) == 448 and callable(ns["run"])
+    assert [f[0] for f in ns["Gas"]._fields_] == [f[0] for f in _capi.Gas._fields_]
+    assert len(ns["lib"].fiveeq_run_f64.argtypes) == len(_capi.SIGNATURES["fiveeq_run_f64"][1])
