@@ -755,10 +755,14 @@ __device__ __forceinline__ HistRule<double> make_rule(const double, const double
     return HistRule<double>{lo, inv_w, (double)(n_bins - 1)};
 }
 __device__ __forceinline__ HistRule<float> make_rule(const float, const double lo, const double inv_w, const int n_bins) {
+    // scale and offset are kept FINITE (a range narrower than ~1e-35 would overflow them): pos is then never inf - inf, so a
+    // finite or infinite member always clamps into [0, n_bins - 1] and no index can leave the histogram
+    const double big = 3.0e38;
+    const float scale = (float)fmin(fmax(inv_w, -big), big), offset = (float)fmin(fmax(-lo * inv_w, -big), big);
 #ifdef FIVEEQ_BIN_RULE_F64
-    return HistRule<float>{(float)inv_w, (float)(-lo * inv_w), (float)(n_bins - 1), lo, inv_w};
+    return HistRule<float>{scale, offset, (float)(n_bins - 1), lo, inv_w};
 #else
-    return HistRule<float>{(float)inv_w, (float)(-lo * inv_w), (float)(n_bins - 1)};
+    return HistRule<float>{scale, offset, (float)(n_bins - 1)};
 #endif
 }
 __device__ __forceinline__ unsigned int hist_bin(const HistRule<double> r, const double v) {

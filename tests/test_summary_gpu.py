@@ -231,3 +231,22 @@ def test_hip_passes_against_their_numpy_restatement():
         for k in range(K):                                                          # ... and the picks are np.sort's order statistics
             srt = np.sort(x64[k][~np.isnan(x64[k])])
             assert np.array_equal(out["hip"][2][k], srt[want[k]])
+
+
+def test_a_range_too_narrow_for_fp32_constants_still_bins_every_member():
+    """hi - lo = 1e-40: n_bins / (hi - lo) overflows a float.  The fp32 bin rule keeps its two constants finite, so every member
+    still lands inside the histogram (below lo -> first bin, above -> last), for the scalar entry point and the ranged one."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    n, nb = 100_000, 4096
+    x = torch.linspace(-1.0, 1.0, n, device="cuda", dtype=torch.float32).reshape(1, n).contiguous()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    h = torch.zeros((1, nb), dtype=torch.int64, device="cuda")
+    _capi.check(lib, lib.fiveeq_hist_rows_f32(1, n, n, p(x), 0.0, 1e-40, nb, p(h), None))
+    rg = torch.tensor([[0.0, 1e-40]], dtype=torch.float64, device="cuda")
+    h2 = torch.zeros((1, nb), dtype=torch.int64, device="cuda")
+    _capi.check(lib, lib.fiveeq_hist_rows_ranged_f32(1, n, n, p(x), p(rg), nb, p(h2), None))
+    torch.cuda.synchronize()
+    for hh in (h, h2):
+        c = hh.cpu().numpy()[0]
+        assert c.sum() == n and c[0] >= (x <= 0).sum().item() - 1 and c[0] + c[-1] == n
