@@ -5,7 +5,8 @@
 set -u
 TAG=${1:-r04}; S=gpurun_out/$TAG; D=profiles/${TAG%k}; mkdir -p $D
 for f in $S/bench_*.json $S/sq_counters_*.csv; do [ -f "$f" ] && cp "$f" $D/; done
-[ "$TAG" = "${TAG%k}" ] && for f in $S/*.txt; do [ -f "$f" ] && cp "$f" $D/; done     # the tables come from collect_profiles.sh only
+# the tables come from collect_profiles.sh only; *_ab.txt are hand-labelled A/B records: never overwritten from scratch
+[ "$TAG" = "${TAG%k}" ] && for f in $S/*.txt; do case "$f" in *_ab.txt) ;; *) [ -f "$f" ] && cp "$f" $D/;; esac; done
 for f in valu.json traffic.json; do [ -f $S/$f ] && cp $S/$f $D/$f && cp $S/$f profiles/$f; done
 for n in fetch_1000000 write_1000000 fetch_8000000 write_8000000 fetch_fused write_fused; do
   src=$(ls -t $S/pmc_$n/*/*counter_collection.csv 2>/dev/null | head -1)
