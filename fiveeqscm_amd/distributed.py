@@ -112,17 +112,39 @@ def merge_moments(parts):
     return out
 
 
+def linear_positions(n, percentiles):
+    """NumPy's 'linear' percentile rule, operation for operation (numpy/lib/_function_base_impl.py: the 'linear' entry of
+    _QuantileMethods, _get_indexes, _get_gamma): for each percentile the two order-statistic indices (i0, i1) of an n-member
+    row and the weight gamma.  Returns (i0 [P] int64, i1 [P] int64, gamma [P] float64) as NumPy arrays.  With `lerp` below the
+    result is np.percentile's BIT FOR BIT (fp64 rows) once the order statistics are exact."""
+    q = np.true_divide(np.asarray(percentiles, dtype=np.float64), 100)
+    virtual = (n - 1) * q
+    prev = np.floor(virtual)
+    nxt = prev + 1.0
+    above, below = virtual >= n - 1, virtual < 0
+    prev[above], nxt[above] = -1.0, -1.0
+    prev[below], nxt[below] = 0.0, 0.0
+    gamma = virtual - prev                                   # (with prev = -1 above the bounds, like NumPy: both ends are the max then)
+    i0, i1 = prev.astype(np.int64) % n, nxt.astype(np.int64) % n
+    return i0, i1, gamma
+
+
+def lerp(a, b, t):
+    """numpy's _lerp: a + (b - a) t, and b - (b - a)(1 - t) where t >= 0.5 (NumPy arrays or torch tensors, broadcasting)."""
+    d = b - a
+    lo = a + d * t
+    hi = b - d * (1.0 - t)
+    if isinstance(lo, torch.Tensor):
+        return torch.where(torch.as_tensor(t >= 0.5, device=lo.device).expand_as(lo), hi, lo)
+    return np.where(np.broadcast_to(t >= 0.5, lo.shape), hi, lo)
+
+
 def percentiles_sorted(xs, percentiles):
-    """xs [K, n] sorted along dim 1 -> [K, len(percentiles)], NumPy 'linear' definition."""
-    n = xs.shape[1]
-    cols = []
-    for p in percentiles:
-        pos = (float(p) / 100.0) * (n - 1)
-        lo = int(pos)
-        hi = min(lo + 1, n - 1)
-        frac = pos - lo
-        cols.append(xs[:, lo] + (xs[:, hi] - xs[:, lo]) * frac)
-    return torch.stack(cols, dim=1)
+    """xs [K, n] sorted along dim 1 -> [K, len(percentiles)], NumPy 'linear' definition (bit for bit in fp64)."""
+    i0, i1, gamma = linear_positions(xs.shape[1], percentiles)
+    a = xs[:, torch.from_numpy(i0).to(xs.device)]
+    b = xs[:, torch.from_numpy(i1).to(xs.device)]
+    return lerp(a, b, torch.from_numpy(gamma).to(device=xs.device, dtype=xs.dtype).reshape(1, -1))
 
 
 def moments_from_sums(sums):
@@ -232,10 +254,9 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
     if exchange:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     cdf = torch.cumsum(counts, dim=1)                                              # [K, n_bins], last = n_total
-    pos = [float(p) / 100.0 * (n_total - 1) for p in percentiles]
-    i0 = [int(v) for v in pos]                                                     # order-statistic indices (floor)
-    i1 = [min(v + 1, n_total - 1) for v in i0]
-    frac = torch.tensor([a - b for a, b in zip(pos, i0)], dtype=f64, device=dev)
+    i0_np, i1_np, gamma_np = linear_positions(n_total, percentiles)               # order-statistic indices, NumPy's rule
+    i0, i1 = i0_np.tolist(), i1_np.tolist()
+    frac = torch.from_numpy(gamma_np).to(device=dev, dtype=f64)
     i0_t = torch.tensor(i0, dtype=torch.int64, device=dev)
     i1_t = torch.tensor(i1, dtype=torch.int64, device=dev)
     want = torch.stack([i0_t, i1_t], dim=1).reshape(1, 2 * P)
@@ -326,7 +347,7 @@ def exact_percentiles(rows, percentiles, gmin, gmax, n_total, dst=0, group=None,
         k, j = [int(v) for v in torch.nonzero(bad)[0].tolist()]
         raise RuntimeError(f"percentile selection lost its order statistic (row {k}, p={percentiles[j]}): "
                            f"{int(at0[k, j] - seg_start[k])},{int(at1[k, j] - seg_start[k])} of {int(seg[k])} candidates")
-    out = c0 + (c1 - c0) * frac.reshape(1, P)
+    out = lerp(c0, c1, frac.reshape(1, P))
     return torch.where(live, out, lo_t.reshape(K, 1).expand(K, P))
 
 
@@ -442,7 +463,8 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
             parts = _all_gather_np(dist, group, world, mine, dev) if exchange else mine[None]
             cnt, s1 = parts[:, :, 0], parts[:, :, 1]
             mean_r = s1 / cnt
-            m2_r = np.maximum(parts[:, :, 2] - cnt * mean_r * mean_r, 0.0)
+            with np.errstate(invalid="ignore", over="ignore"):
+                m2_r = np.maximum(parts[:, :, 2] - cnt * mean_r * mean_r, 0.0)
             mom = merge_moments(torch.from_numpy(np.stack([cnt, mean_r, m2_r, parts[:, :, 3], parts[:, :, 4]], axis=2))).numpy()
         if gmin is None:
             lo_np, hi_np, n_tot = mom[:, 3].copy(), mom[:, 4].copy(), int(round(float(mom[0, 0])))
@@ -467,7 +489,8 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
         sums_np = head_np[K * n_bins:].view(np.float64).reshape(K, 4)
         cnt = np.full(K, float(n_local))
         mean_r = sums_np[:, 0] / cnt
-        mom = np.stack([cnt, mean_r, np.maximum(sums_np[:, 1] - cnt * mean_r * mean_r, 0.0), sums_np[:, 2], sums_np[:, 3]], axis=1)
+        with np.errstate(invalid="ignore", over="ignore"):       # a row with an infinite member: its moments are inf / nan, quietly
+            mom = np.stack([cnt, mean_r, np.maximum(sums_np[:, 1] - cnt * mean_r * mean_r, 0.0), sums_np[:, 2], sums_np[:, 3]], axis=1)
         lo_np, hi_np = sums_np[:, 2].copy(), sums_np[:, 3].copy()
     cdf = np.cumsum(counts_np, axis=1)
     # a NaN member has no bin: a row whose counts do not add up to the member count holds one, and np.percentile of it is NaN
@@ -476,10 +499,7 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
         stats["bytes_to_root"], stats["allreduce_bytes"] = 0, (counts.numel() * 8 if exchange else 0)
 
     # ---- host: the bins that hold the wanted order statistics, and each statistic's rank among the members of marked bins ---
-    pos = np.array([float(p) / 100.0 * (n_tot - 1) for p in percentiles])
-    i0 = np.floor(pos).astype(np.int64)
-    i1 = np.minimum(i0 + 1, n_tot - 1)
-    frac = pos - i0
+    i0, i1, frac = linear_positions(n_tot, percentiles)
     want = np.concatenate([i0, i1])                                                     # [2P] global order-statistic indices
     bb = np.stack([np.searchsorted(cdf[k], want, side="right") for k in range(K)]).clip(max=n_bins - 1)     # [K, 2P]
     flat = ~(hi_np > lo_np)                              # a constant row: every member IS the answer, nothing to select
@@ -559,7 +579,7 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
             k, j = [int(v) for v in np.argwhere(~good)[0]]
             raise RuntimeError(f"percentile selection lost its order statistic (row {k}, p={percentiles[j]}): ranks "
                                f"{int(ranks[k, j])},{int(ranks[k, j + P])} of {int(tot_c[k])} candidates, values {c0[k, j]}, {c1[k, j]}")
-        out = c0 + (c1 - c0) * frac[None, :]
+        out = lerp(c0, c1, frac[None, :])
     out = np.where(nan_row[:, None], np.nan, np.where(flat[:, None], np.broadcast_to(lo_np[:, None], (K, P)), out))
     return mom, out
 

@@ -313,7 +313,7 @@ def _worker_passes(rank, world, port, n_total, q):
             s = gather_summary(mine, percentiles=pct, stats=st)
             if rank == 0:
                 x = full.astype(dt).astype(np.float64)
-                ok = ok and np.allclose(s["percentiles"].numpy(), np.percentile(x, pct, axis=1).T, rtol=1e-14, atol=0)
+                ok = ok and np.array_equal(s["percentiles"].numpy(), np.percentile(x, pct, axis=1).T)      # bit for bit
                 ok = ok and np.allclose(s["mean"].numpy(), x.mean(1), rtol=1e-12) and np.allclose(s["var"].numpy(), x.var(1), rtol=1e-9)
                 ok = ok and np.array_equal(s["min"].numpy(), x.min(1)) and np.array_equal(s["max"].numpy(), x.max(1))
                 ok = ok and s["count"].tolist() == [float(n_total)] * 5 and st["allreduce_bytes"] == 5 * 4096 * 8
@@ -361,10 +361,10 @@ def test_pass_based_summary_edge_cases_on_cpu(monkeypatch):
                 out = gather_summary(torch.from_numpy(xs), pct)
                 x64 = xs.astype(np.float64)
                 want = np.percentile(x64, pct, axis=1).T
-                np.testing.assert_allclose(out["percentiles"].numpy(), want, rtol=1e-14, atol=0, err_msg=f"n={n} {dt}")
+                assert np.array_equal(out["percentiles"].numpy(), want), f"n={n} {dt}"        # np.percentile BIT FOR BIT
                 np.testing.assert_allclose(out["mean"].numpy(), x64.mean(1), rtol=1e-12, atol=1e-13)
                 sel = exact_percentiles(torch.from_numpy(xs), pct, torch.from_numpy(x64.min(1)), torch.from_numpy(x64.max(1)), n)
-                np.testing.assert_allclose(sel.numpy(), want, rtol=1e-14, atol=0)
+                assert np.array_equal(sel.numpy(), want)
         # a row of heavy ties beside ordinary rows: past SELECT_CAND_BYTES the rows are summarised in halves, recursively
         monkeypatch.setattr(distributed, "SELECT_CAND_BYTES", 20_000)
         z = rng.normal(size=(7, 3000))
@@ -381,5 +381,32 @@ def test_pass_based_summary_edge_cases_on_cpu(monkeypatch):
         np.testing.assert_allclose(out["percentiles"].numpy()[0], np.percentile(y[0], (5.0, 50.0, 95.0)), rtol=1e-14)
         assert np.isnan(out["percentiles"].numpy()[1]).all() and np.isnan(out["mean"][1].item())
         assert out["min"][1].item() == np.nanmin(y[1]) and out["max"][1].item() == np.nanmax(y[1])
+    finally:
+        distributed._lib_and_stream, distributed._passes_apply = saved
+
+
+def test_pass_based_summary_fuzz_against_numpy_percentile():
+    """300 random shapes: 1-5 rows of 1-5000 members, six distributions (incl. constant rows, heavy ties, values of 1e-30
+    spread, 1e6-scaled Cauchy), fp32 and fp64, 1-8 random percentiles with repeats, infinite members thrown in — the result is
+    np.percentile's bit for bit (NaN where NumPy's interpolation gives NaN)."""
+    from fiveeqscm_amd import distributed
+    saved = distributed._lib_and_stream, distributed._passes_apply
+    try:
+        _use_oracle_passes()
+        rng = np.random.default_rng(0)
+        grid = [0, 0.1, 1, 5, 25, 33.3, 50, 50.01, 75, 95, 99.9, 100]
+        for it in range(300):
+            K, n, kind = int(rng.integers(1, 6)), int(rng.choice([1, 2, 3, 7, 64, 65, 100, 1000, 5000])), int(rng.integers(0, 6))
+            x = (lambda: rng.normal(size=(K, n)), lambda: rng.uniform(size=(K, n)) ** 5, lambda: np.round(rng.normal(size=(K, n)) * 2) / 2,
+                 lambda: rng.standard_cauchy(size=(K, n)) * 1e6, lambda: np.full((K, n), 3.25),
+                 lambda: rng.normal(size=(K, n)) * 1e-30 + 1e-3)[kind]()
+            if rng.uniform() < 0.2 and n > 2:
+                x[rng.integers(0, K), rng.integers(0, n)] = np.inf * rng.choice([-1, 1])
+            xs = x.astype(np.float32 if rng.uniform() < 0.5 else np.float64)
+            pct = tuple(float(v) for v in rng.choice(grid, size=int(rng.integers(1, 9))))
+            got = gather_summary(torch.from_numpy(xs), pct)["percentiles"].numpy()
+            with np.errstate(invalid="ignore"):
+                want = np.percentile(xs.astype(np.float64), pct, axis=1).T
+            assert np.array_equal(got, want, equal_nan=True), (it, K, n, kind, xs.dtype, pct)
     finally:
         distributed._lib_and_stream, distributed._passes_apply = saved
