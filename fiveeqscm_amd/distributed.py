@@ -402,6 +402,11 @@ def device_row_sums(rows, out=None):
     propagate them.  `out`: a [K, 4] fp64 device tensor to write into."""
     lib, _capi, ctypes, st = _lib_and_stream(rows)
     K, n = rows.shape
+    if n == 0:                                         # an empty shard (fewer members than ranks): the neutral record
+        if out is None:
+            out = torch.empty((K, 4), dtype=torch.float64, device=rows.device)
+        out.copy_(torch.tensor([0.0, 0.0, float("inf"), float("-inf")], dtype=torch.float64).expand(K, 4))
+        return out
     chunks = int(lib.fiveeq_row_moments_chunks(K, n))
     work = torch.empty((K * chunks + (K if out is None else 0)) * 4, dtype=torch.float64, device=rows.device)
     if out is None:
@@ -462,6 +467,10 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
             mine = np.concatenate([np.full((K, 1), float(n_local)), sums_dev.cpu().numpy()], axis=1)      # [K, 5]
             parts = _all_gather_np(dist, group, world, mine, dev) if exchange else mine[None]
             cnt, s1 = parts[:, :, 0], parts[:, :, 1]
+            keep = cnt[:, 0] > 0                                 # ranks whose shard is empty take no part in the merge
+            parts, cnt, s1 = parts[keep], cnt[keep], s1[keep]
+            if parts.shape[0] == 0:
+                raise ValueError("gather_summary: no members on any rank")
             mean_r = s1 / cnt
             with np.errstate(invalid="ignore", over="ignore"):
                 m2_r = np.maximum(parts[:, :, 2] - cnt * mean_r * mean_r, 0.0)
@@ -478,9 +487,10 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
         n_tot = n_local
 
     # ---- pass 2: histograms between the global extrema ------------------------------------------------------------------
-    with _on(dev):
-        _capi.check(lib, getattr(lib, f"fiveeq_hist_rows_ranged_{sfx}")(K, n_local, ld, ptr(rows), ptr(ranges), n_bins,
-                                                                        ptr(counts), st))
+    if n_local > 0:
+        with _on(dev):
+            _capi.check(lib, getattr(lib, f"fiveeq_hist_rows_ranged_{sfx}")(K, n_local, ld, ptr(rows), ptr(ranges), n_bins,
+                                                                            ptr(counts), st))
     if exchange:
         _all_reduce(dist, group, counts, dist.ReduceOp.SUM)
     head_np = head.cpu().numpy()                          # THE device-to-host copy of a one-rank summary's first half
@@ -499,6 +509,8 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
         stats["bytes_to_root"], stats["allreduce_bytes"] = 0, (counts.numel() * 8 if exchange else 0)
 
     # ---- host: the bins that hold the wanted order statistics, and each statistic's rank among the members of marked bins ---
+    if n_tot < 1:
+        raise ValueError("gather_summary: no members on any rank")
     i0, i1, frac = linear_positions(n_tot, percentiles)
     want = np.concatenate([i0, i1])                                                     # [2P] global order-statistic indices
     bb = np.stack([np.searchsorted(cdf[k], want, side="right") for k in range(K)]).clip(max=n_bins - 1)     # [K, 2P]
@@ -538,7 +550,8 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
     tail = torch.zeros(K + K * Q, dtype=torch.int64, device=dev)
     cand = torch.empty((K, cap), dtype=rows.dtype, device=dev)
     with _on(dev):
-        _capi.check(lib, select(K, n_local, ld, ptr(rows), ptr(ranges), n_bins, ptr(up, o_mask), ptr(cand), cap, ptr(tail), st))
+        if n_local > 0:
+            _capi.check(lib, select(K, n_local, ld, ptr(rows), ptr(ranges), n_bins, ptr(up, o_mask), ptr(cand), cap, ptr(tail), st))
         if not exchange:
             _capi.check(lib, pick(K, 1, cap, ptr(cand), ptr(tail), Q, ptr(up), ptr(tail, K * 8), st))
     tail_np = tail.cpu().numpy()                          # one rank: THE second (and last) device-to-host copy

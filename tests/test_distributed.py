@@ -410,3 +410,50 @@ def test_pass_based_summary_fuzz_against_numpy_percentile():
             assert np.array_equal(got, want, equal_nan=True), (it, K, n, kind, xs.dtype, pct)
     finally:
         distributed._lib_and_stream, distributed._passes_apply = saved
+
+
+def _worker_fuzz(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    _use_oracle_passes()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(77)                       # the same stream on every rank: each rebuilds the global rows
+        grid = [0, 1, 5, 33.3, 50, 50.01, 95, 99.9, 100]
+        bad = []
+        for it in range(60):
+            K, n_total, kind = int(rng.integers(1, 5)), int(rng.choice([1, 2, 3, 5, 64, 200, 3001])), int(rng.integers(0, 4))
+            full = (lambda: rng.normal(size=(K, n_total)), lambda: np.round(rng.normal(size=(K, n_total))),
+                    lambda: rng.standard_cauchy(size=(K, n_total)), lambda: np.full((K, n_total), -1.5))[kind]()
+            dt = np.float32 if rng.uniform() < 0.5 else np.float64
+            pct = tuple(float(v) for v in rng.choice(grid, size=int(rng.integers(1, 6))))
+            lo, hi = shard_bounds(n_total, rank, world)       # n_total < world: some shards are EMPTY
+            s = gather_summary(torch.from_numpy(np.ascontiguousarray(full[:, lo:hi].astype(dt))), percentiles=pct)
+            x = full.astype(dt).astype(np.float64)
+            if rank == 0:
+                if not (np.array_equal(s["percentiles"].numpy(), np.percentile(x, pct, axis=1).T)
+                        and np.allclose(s["mean"].numpy(), x.mean(1), rtol=1e-12, atol=1e-12 * max(1.0, np.abs(x[np.isfinite(x)]).max()))
+                        and np.array_equal(s["min"].numpy(), x.min(1)) and s["count"].tolist() == [float(n_total)] * K):
+                    bad.append((it, K, n_total, kind, dt.__name__, pct))
+            elif s["percentiles"] is not None or s["count"].tolist() != [float(n_total)] * K:
+                bad.append((it, "non-root"))
+        q.put(bad)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pass_based_summary_fuzz_over_three_ranks_incl_empty_shards():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fuzz, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == [[], [], []], results
