@@ -297,11 +297,13 @@ class EnsembleEngine:
     def auto_k_steps(self):
         """Steps per launch for mode='auto': 1 (the per-step kernel) while one step's HBM traffic hides the
         dependent-launch boundary, otherwise the K that brings a launch's traffic time to ~3 boundaries
-        (capped at 16): small ensembles are launch-bound, not bandwidth-bound."""
+        (capped at 32: a launch costs ~2.6 us beside ~0.75 us per step of a 10k-member ensemble — 0.92 us/step at K = 16,
+        0.84 at 32, 0.75 fully fused, profiles/r03/in_loop_hist_config5_shard_f32.txt): small ensembles are launch-bound,
+        not bandwidth-bound."""
         t_step = self.n_members * self.bytes_per_member_step("per_step") / HBM_STREAM_BYTES_PER_S
         if t_step >= 3.0 * LAUNCH_BOUNDARY_S:
             return 1
-        return int(min(16, max(2, round(3.0 * LAUNCH_BOUNDARY_S / max(t_step, 1e-9)))))
+        return int(min(32, max(2, round(3.0 * LAUNCH_BOUNDARY_S / max(t_step, 1e-9)))))
 
     # -- state -------------------------------------------------------------------------
     def reset_state(self):
