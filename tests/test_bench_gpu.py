@@ -184,14 +184,18 @@ def test_an_rccl_failure_on_first_contact_costs_the_summary_not_the_measurement(
 def test_a_host_bound_multi_rank_run_falls_back_to_graph_replay():
     """N > 1, no explicit --mode: if the slowest rank's host thread needs more than --host-share-limit of a step to enqueue
     it, the timed region runs the hipGraph replay of the same launches (same kernels, same bits).  Forced here with a limit
-    of 0; the default limit leaves the per-step form in place; an explicit --mode is never overridden."""
+    of 0 and excluded with a limit of 100; the default limit decides by this box's measured share; an explicit --mode is
+    never overridden."""
     forced = _one_line(_plain(2, *_SMALL, "--host-share-limit", "0"))
     assert forced["config"]["mode"] == "graph" and forced["config"]["mode_requested"] == "default"
     fb = forced["timing"]["host_fallback"]
     assert fb["switched_to_graph"] is True and fb["per_step_host_share"] > 0 and fb["limit"] == 0.0
-    kept = _one_line(_plain(2, *_SMALL))
+    kept = _one_line(_plain(2, *_SMALL, "--host-share-limit", "100"))               # a limit no box reaches: never switches
     assert kept["config"]["mode"] == "per_step" and kept["timing"]["host_fallback"]["switched_to_graph"] is False
-    assert kept["timing"]["host_fallback"]["per_step_host_share"] < 0.5
+    default = _one_line(_plain(2, *_SMALL))                                          # the default limit: whatever this box's share says
+    fb_d = default["timing"]["host_fallback"]
+    assert fb_d["limit"] == 0.5 and fb_d["switched_to_graph"] == (fb_d["per_step_host_share"] >= 0.5)
+    assert default["config"]["mode"] == ("graph" if fb_d["switched_to_graph"] else "per_step")
     _summaries_agree(forced["summary"], kept["summary"], rel=0.0)                  # bit-identical kernels
     assert forced["timing"]["host_enqueue_us_per_step"] < kept["timing"]["host_enqueue_us_per_step"]
     explicit = _one_line(_plain(2, *_SMALL, "--mode", "per_step", "--host-share-limit", "0"))
