@@ -1524,3 +1524,58 @@ def test_per_step_histograms_use_a_one_slot_bin_ring(gpu):
     a.run(mode="fused")
     assert tuple(a._bins["buf"].shape) == (2, 16, N) and torch.equal(a.T_hist, per_step)
     a.close()
+
+
+def test_random_sequences_of_segments_modes_and_checkpoints(gpu):
+    """30 random runs cut into 2-5 consecutive segments, every segment in another launch shape (per-step, fused, K-step,
+    tiled, graph replay, auto — with hist= the forms that fill T_hist), one checkpoint somewhere on the way restored into a
+    FRESH engine (reduced outputs or raw buffers), fp64 / fp32, bin-index or T ring, stored concentrations or not: state, stored
+    rows, histograms and per-step moments at the end must be those of ONE per-step run of the whole range."""
+    rng = np.random.default_rng(404)
+    for case in range(30):
+        N = int(rng.choice([1, 63, 64, 65, 257, 1024, 2049, 5000, 20_011]))
+        n_steps = int(rng.integers(20, 90))
+        kind, G = (("multigas", 3), ("co2", 1))[int(rng.integers(0, 2))]
+        td = (torch.float64, torch.float32)[int(rng.integers(0, 2))]
+        with_hist = bool(rng.integers(0, 2))
+        ring = ("bins", "T")[int(rng.integers(0, 2))]
+        store_c = bool(rng.integers(0, 2)) and not (with_hist and ring == "T")          # a T ring carries T only
+        kw = dict(dtype=td, store_concentrations=store_c, collect_stats=True, hist_ring=ring,
+                  hist=(-0.5, float(rng.uniform(2.0, 6.0)), int(rng.choice([64, 1000, 4096]))) if with_hist else None,
+                  hist_ring_steps=int(rng.integers(2, 20)))
+        p = prm.sample_ensemble(prm.default_params(kind), N, seed=1000 + case)
+        E = emi.rcp_like_emissions(750, G)[220:220 + n_steps] * float(rng.uniform(0.5, 2.0))
+        ref = _engine(p, N, E, **kw)
+        ref.run(mode="per_step")
+        cuts = sorted(set([0, n_steps] + [int(v) for v in rng.integers(1, n_steps, size=int(rng.integers(1, 5)))]))
+        modes = ["per_step", "fused", "tiled", "auto"] if with_hist else ["per_step", "fused", "ksteps", "tiled", "graph", "auto"]
+        ck_at = int(rng.integers(1, len(cuts) - 1)) if len(cuts) > 2 else None            # checkpoint BEFORE this segment
+        raw = bool(rng.integers(0, 2))
+        eng, first_row, log = _engine(p, N, E, **kw), 0, []
+        for i in range(len(cuts) - 1):
+            if ck_at is not None and i == ck_at:
+                state = eng.state_dict(include_outputs=True if raw else "summaries")
+                eng.close()
+                eng = _engine(p, N, E, **kw)
+                eng.load_state_dict(state)
+                first_row = 0 if raw else cuts[i]                                     # "summaries" do not carry stored rows
+                log.append(("checkpoint", "raw" if raw else "summaries", cuts[i]))
+            mode = modes[int(rng.integers(0, len(modes)))]
+            k = int(rng.integers(1, 12)) if mode in ("ksteps", "tiled") else None
+            if mode == "tiled":
+                k = min(k, eng.tile_steps())
+            eng.run(cuts[i], cuts[i + 1], mode=mode, k_steps=k)
+            log.append((mode, k, cuts[i], cuts[i + 1]))
+        torch.cuda.synchronize()
+        what = (case, N, n_steps, kind, td, kw["hist"], ring, store_c, log)
+        assert torch.equal(eng.R, ref.R) and torch.equal(eng.S, ref.S), what
+        assert torch.equal(eng.T[first_row:], ref.T[first_row:]), what
+        if store_c:
+            assert torch.equal(eng.C[first_row:], ref.C[first_row:]), what
+        if with_hist:
+            assert torch.equal(eng.T_hist, ref.T_hist), what
+        a, b = eng.stats_sums(), ref.stats_sums()
+        assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]), what
+        assert torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-11, atol=1e-9), what
+        assert eng.state_dict()["_step_sums_valid"].all(), what
+        eng.close(), ref.close()
