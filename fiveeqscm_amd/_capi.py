@@ -93,6 +93,9 @@ SIGNATURES = {
     "fiveeq_run_inverse_f32": (ctypes.c_int, _RUN_ARGS[:11] + [_p] + _RUN_ARGS[11:]),
     "fiveeq_run_ksteps_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
     "fiveeq_run_ksteps_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
+    "fiveeq_run_small_f64": (ctypes.c_int, _RUN_ARGS[:-2] + [_i32, _p]),
+    "fiveeq_run_small_f32": (ctypes.c_int, _RUN_ARGS[:-2] + [_i32, _p]),
+    "fiveeq_small_lanes": (_i32, [_i32, ctypes.POINTER(_i32)]),
     "fiveeq_run_tiled_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
     "fiveeq_run_tiled_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
     "fiveeq_tile_steps_f64": (_i32, [_i32]),

@@ -336,6 +336,50 @@ int run_ksteps(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int
     return FIVEEQ_OK;
 }
 
+// ---- small ensembles: one member per quad of lanes (small_kernel) ------------------------------------
+// lanes per member of the widest small-ensemble form compiled for a layout: 4 for a lone 4-pool gas, 1 for any other
+// single-gas layout, 0 = none (several gases)
+int small_lanes(int code) {
+    switch (code) {
+        case 400: return 4;
+        case 100: case 200: case 300: return 1;
+        default: return 0;
+    }
+}
+
+template <typename T>
+int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
+              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, int32_t lanes,
+              void* stream) {
+    RunArgs<T> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, nullptr)) return rc;
+    const int widest = small_lanes(a.code);
+    if (widest == 0) return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no small-ensemble kernel", a.code);
+    if (lanes == 0) lanes = widest;
+    if (lanes != 1 && lanes != widest)
+        return fail(FIVEEQ_E_INVALID, "lanes_per_member=%d: pool layout %03d takes 1%s", lanes, a.code, widest == 4 ? " or 4" : "");
+    if (t_begin == t_end) return FIVEEQ_OK;
+    const int64_t per_block = FIVEEQ_SMALL_BLOCK / lanes;
+    const int64_t blocks = (a.n + per_block - 1) / per_block;
+    if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
+    const dim3 grid((unsigned)blocks), block(FIVEEQ_SMALL_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+#define FIVEEQ_SMALL(p0, lpm)                                                                                       \
+    hipLaunchKernelGGL((small_kernel<T, p0, lpm>), grid, block, 0, st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, \
+                       a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows)
+    switch (a.code * 10 + lanes) {
+        case 1001: FIVEEQ_SMALL(1, 1); break;
+        case 2001: FIVEEQ_SMALL(2, 1); break;
+        case 3001: FIVEEQ_SMALL(3, 1); break;
+        case 4001: FIVEEQ_SMALL(4, 1); break;
+        case 4004: FIVEEQ_SMALL(4, 4); break;
+        default: return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no small-ensemble kernel", a.code);
+    }
+#undef FIVEEQ_SMALL
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
 // ---- time-tiled persistent kernel with in-loop histograms ---------------------------------------
 // LDS a workgroup may use, from the device (hipDeviceAttributeMaxSharedMemoryPerBlock: 160 KiB on MI355X), asked once per
 // thread and device.  Without a device (the CPU build container, where only the argument checks run) the gfx950 figure is
@@ -551,6 +595,9 @@ const char* fiveeq_build_flags(void) {
 #if FIVEEQ_BLOCK != 256
            " FIVEEQ_BLOCK=" FIVEEQ_STR(FIVEEQ_BLOCK)
 #endif
+#if FIVEEQ_SMALL_BLOCK != 256
+           " FIVEEQ_SMALL_BLOCK=" FIVEEQ_STR(FIVEEQ_SMALL_BLOCK)
+#endif
 #if FIVEEQ_STEP_BLOCK != 64
            " FIVEEQ_STEP_BLOCK=" FIVEEQ_STR(FIVEEQ_STEP_BLOCK)
 #endif
@@ -698,6 +745,24 @@ int fiveeq_run_tiled_f32(const fiveeq_model* model, int64_t n_members, int64_t l
                          double hist_lo, double hist_hi, int32_t n_bins, uint64_t* T_hist, void* stream) {
     return run_tiled<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
                             T_stats, k_steps, hist_lo, hist_hi, n_bins, T_hist, stream);
+}
+int fiveeq_run_small_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
+                         int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
+                         double* S, double* C_traj, double* T_traj, int32_t n_rows, int32_t lanes_per_member, void* stream) {
+    return run_small<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                             lanes_per_member, stream);
+}
+int fiveeq_run_small_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
+                         int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
+                         float* S, float* C_traj, float* T_traj, int32_t n_rows, int32_t lanes_per_member, void* stream) {
+    return run_small<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                            lanes_per_member, stream);
+}
+int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t* n_pools) {
+    if (!fiveeq_layout_supported(n_gas, n_pools)) return 0;
+    int p[3] = {0, 0, 0};
+    for (int g = 0; g < n_gas; ++g) p[g] = n_pools[g];
+    return small_lanes(p[0] * 100 + p[1] * 10 + p[2]);
 }
 int fiveeq_set_f32_packing(int on) {
     const int prev = g_f32_packing;

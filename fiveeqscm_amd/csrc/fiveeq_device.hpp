@@ -36,6 +36,9 @@
 #endif
 // (Experiments that lost — device-library math, non-temporal trajectory stores, model constants in SGPRs —
 // are recorded in profiles/r01/ab_variants.txt; their code paths are gone.)
+#ifndef FIVEEQ_SMALL_BLOCK
+#define FIVEEQ_SMALL_BLOCK 256    // threads per workgroup of the small-ensemble kernel: four waves, one per SIMD of a CU (measured, below)
+#endif
 #ifndef FIVEEQ_FUSED_CHUNK
 #define FIVEEQ_FUSED_CHUNK 125    // drive-table steps staged into LDS per refill (fused kernel)
 #endif
@@ -1000,6 +1003,176 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
         if constexpr (INV) {
 #pragma unroll
             for (int g = 0; g < L::G; ++g) cumE[g * ld + m] = cum[g];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel 2c — SMALL ENSEMBLES: the time-fused step with ONE MEMBER SPREAD OVER A QUAD OF LANES (round 5).
+//
+// A 10k-member ensemble (BASELINE configs[1]) is 157 waves for 1024 SIMDs: every wave is alone on its SIMD, and a lone
+// wave issues one vector instruction per ~3.7-4.2 ns whatever the instruction and however independent its neighbours are
+// (tools/microbench/valu_rates.hip, "waves/SIMD 1": 9-10 nominal cycles for v_fma_f64 and for v_mov_b32 alike).  What such
+// a run costs is therefore the NUMBER OF INSTRUCTIONS ONE WAVE ISSUES PER STEP — not bytes, not FLOPs, not occupancy — and
+// the way to shorten it is to hand parts of a member's step to lanes that would otherwise not exist:
+//   * LPM = 4 (layouts with a 4-pool gas and nothing else: CO2-only): lane 4m + i carries POOL i of member m.  Its expm1,
+//     its pool update and its slice of the state are the lane's own (one expm1 chain per wave-step instead of four); the
+//     alpha closure, the forcing and the thermal boxes are computed by all four lanes alike (redundant lanes are free:
+//     the instruction is issued once per wave either way).  The two sums over pools are folded with quad_perm DPP moves
+//     in the per-step kernel's order ((R0 + R1) + R2) + R3, every lane of the quad computing the same sum from the same
+//     four values: the bits do not change.  4x the waves of the one-member-per-lane form, 16 members per wave;
+//   * the shared model is read from the KERNEL ARGUMENT (scalar loads, hoisted out of the time loop) instead of being
+//     re-read from LDS every step: with one wave per SIMD the registers are there (512 VGPRs), and an LDS round trip that
+//     nothing hides is ~100 cycles of the wave's time;
+//   * the step's drive record is read one step AHEAD (LDS, broadcast), so that its latency lies under the previous step.
+// LPM = 1 is the same kernel without the spreading (any single-gas layout): what the register-resident constants buy alone.
+// No per-wave statistics and no histogram ring: those runs take the fused kernel.  Same arithmetic, operation for
+// operation, as member_step(): bit-identical results (tested against the per-step path).
+// ---------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ double quad_bcast(const double v) {           // lane 4q + K of every quad, to the whole quad
+    // (mov_dpp, not update_dpp: every lane has a source, so there is no "old" value to initialise — 16 v_mov less per step)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), K * 0x55, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), K * 0x55, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ float quad_bcast(const float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xf, 0xf, true));
+}
+
+template <typename T, int P0, int LPM>
+__global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void small_kernel(
+    const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
+    const int64_t n, const int64_t ld, const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R,
+    T* __restrict__ S, T* __restrict__ C_traj /* [n_rows][1][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
+    const int n_rows) {
+    static_assert(LPM == 1 || (LPM == 4 && P0 == 4), "a quad of lanes carries the four pools of one gas");
+    constexpr int MPB = FIVEEQ_SMALL_BLOCK / LPM;                        // members per workgroup
+    __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
+    __shared__ int row_s[FIVEEQ_FUSED_CHUNK];                            // the steps' output rows, converted once per chunk
+    const int lane = threadIdx.x;
+    const int sub = lane % LPM;                                          // the pool this lane carries (LPM = 4)
+    const int64_t m = (int64_t)blockIdx.x * MPB + lane / LPM;
+    const bool active = m < n;
+    const int64_t mm = active ? m : 0;                                   // idle tail lanes shadow member 0 and store nothing
+    const KGas<T>& kg = km.gas[0];                                       // kernel argument: scalar loads, loop-invariant
+
+    T rr[3], qq[2], Sv[2], Rv[LPM == 1 ? P0 : 1];
+    T ndt[LPM == 1 ? P0 : 1], natc[LPM == 1 ? P0 : 1];                  // -dt / tau_i and -(a_i tau_i c) of this lane's pool(s)
+    if constexpr (LPM == 1) {
+#pragma unroll
+        for (int i = 0; i < P0; ++i) Rv[i] = R[i * ld + mm], ndt[i] = kg.ndt_over_tau[i], natc[i] = -kg.atc[i];
+    } else {
+        Rv[0] = R[sub * ld + mm];
+        ndt[0] = sub == 0 ? kg.ndt_over_tau[0] : (sub == 1 ? kg.ndt_over_tau[1] : (sub == 2 ? kg.ndt_over_tau[2] : kg.ndt_over_tau[3]));
+        natc[0] = -(sub == 0 ? kg.atc[0] : (sub == 1 ? kg.atc[1] : (sub == 2 ? kg.atc[2] : kg.atc[3])));
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rr[k] = r[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
+    // LPM = 4: ONE store per step and lane — lane 0 of the quad writes C, lane 1 writes T (its own base pointer; null = this
+    // lane stores nothing)
+    T* const out_q = !active ? nullptr : (sub == 0 ? (C_traj ? C_traj + m : nullptr) : (sub == 1 ? (T_traj ? T_traj + m : nullptr) : nullptr));
+
+    // the sum over pools of the CURRENT state, in the per-step kernel's order ((R0 + R1) + R2) + R3.  Computed here once; each
+    // step's own sum over the NEW pools, (((0 + R0') + R1') + R2') + R3', is then the next step's: the same additions on the
+    // same values (0 + x = x), except that a zero may come out with the other sign, which alpha = g0 exp(iIRF / g1) — the
+    // sum's only consumer — cannot see.
+    T sumR;
+    if constexpr (LPM == 1) {
+        sumR = Rv[0];
+#pragma unroll
+        for (int i = 1; i < P0; ++i) sumR += Rv[i];
+    } else {
+        sumR = quad_bcast<0>(Rv[0]);
+        sumR += quad_bcast<1>(Rv[0]);
+        sumR += quad_bcast<2>(Rv[0]);
+        sumR += quad_bcast<3>(Rv[0]);
+    }
+
+    for (int tc = t_begin; tc < t_end; tc += FIVEEQ_FUSED_CHUNK) {
+        const int nt = min(FIVEEQ_FUSED_CHUNK, t_end - tc);
+        __syncthreads();                                                 // (one wave: the previous chunk is consumed)
+        for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += FIVEEQ_SMALL_BLOCK) {
+            const T v = drive[(int64_t)tc * DRIVE_STRIDE + i];
+            drv[i] = v;
+            if ((i & (DRIVE_STRIDE - 1)) == 7) row_s[i >> 3] = (int)v;
+        }
+        __syncthreads();
+        T E = drv[0], cumE = drv[3], Fx = drv[6];                        // step tc
+        int rowv = row_s[0];
+        for (int k = 0; k < nt; ++k) {
+            const int kn = k + 1 < nt ? k + 1 : k;                       // the NEXT step's record, asked for now
+            const T En = drv[kn * DRIVE_STRIDE], cumEn = drv[kn * DRIVE_STRIDE + 3], Fxn = drv[kn * DRIVE_STRIDE + 6];
+            const int rowvn = row_s[kn];
+            // ---- member_step(), operation for operation (gas_step<.., g = 0, INV = false>) ----
+            const T T_old = Sv[0] + Sv[1];
+            const T G_a = sumR * kg.inv_c;
+            const T G_u = cumE - G_a;
+            T iirf = fe_fma(kg.ra, G_a, fe_fma(rr[2], T_old, fe_fma(rr[1], G_u, rr[0])));
+            iirf = fe_min(iirf, km.iirf_max);
+            const T alpha = kg.g0 * fe_exp(iirf * kg.inv_g1);
+            const T inv_alpha = fe_rcp(alpha);
+            const T Ea = E * alpha;
+            T sumN = T(0);
+            if constexpr (LPM == 1) {
+                T em1[P0];
+#pragma unroll
+                for (int i = 0; i < P0; ++i) em1[i] = fe_expm1_neg(ndt[i] * inv_alpha);
+#pragma unroll
+                for (int i = 0; i < P0; ++i) {
+                    const T Rn = fe_fma(em1[i], fe_fma(natc[i], Ea, Rv[i]), Rv[i]);
+                    Rv[i] = Rn;
+                    sumN += Rn;
+                }
+            } else {
+                const T em1 = fe_expm1_neg(ndt[0] * inv_alpha);
+                const T Rn = fe_fma(em1, fe_fma(natc[0], Ea, Rv[0]), Rv[0]);
+                Rv[0] = Rn;
+                sumN += quad_bcast<0>(Rn);
+                sumN += quad_bcast<1>(Rn);
+                sumN += quad_bcast<2>(Rn);
+                sumN += quad_bcast<3>(Rn);
+            }
+            sumR = sumN;
+            const T Cg = kg.C0 + sumN;
+            const bool pos = Cg > T(0);
+            T Fg = kg.f2 * (Cg - kg.C0);
+            if (kg.f1 != T(0)) Fg = pos ? fe_fma(kg.f1, fe_log(pos ? Cg * kg.inv_C0 : T(1)), Fg) : Fg;
+            if (kg.f3 != T(0)) Fg = fe_fma(kg.f3, (pos ? fe_sqrt(pos ? Cg : T(1)) : T(0)) - kg.sqrtC0, Fg);
+            T F = Fx;
+            F += Fg;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Sv[j] = fe_fma(km.em1_d[j], fe_fma(-qq[j], F, Sv[j]), Sv[j]);
+            const T Tn = Sv[0] + Sv[1];
+            // ---- the step's stored rows ----
+            const int row = __builtin_amdgcn_readfirstlane(rowv);
+            if (row >= 0 && row < n_rows) {
+                if constexpr (LPM == 1) {
+                    if (active) {
+                        if (C_traj != nullptr) C_traj[(int64_t)row * ld + m] = Cg;
+                        if (T_traj != nullptr) T_traj[(int64_t)row * ld + m] = Tn;
+                    }
+                } else {
+                    if (out_q != nullptr) out_q[(int64_t)row * ld] = sub == 0 ? Cg : Tn;
+                }
+            }
+            E = En, cumE = cumEn, Fx = Fxn, rowv = rowvn;
+        }
+    }
+    if (active) {
+        if constexpr (LPM == 1) {
+#pragma unroll
+            for (int i = 0; i < P0; ++i) R[i * ld + m] = Rv[i];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+        } else {
+            R[sub * ld + m] = Rv[0];
+            if (sub < 2) S[sub * ld + m] = sub == 0 ? Sv[0] : Sv[1];
         }
     }
 }

@@ -263,6 +263,7 @@ class EnsembleEngine:
         if fused_span not in ("auto", None) and int(fused_span) < 1:
             raise ValueError("fused_span must be 'auto', None or a positive number of steps")
         self.fused_span = fused_span if fused_span in ("auto", None) else int(fused_span)
+        self.small_lanes = 0                # mode='small': lanes per member (0 = the widest form the layout has)
         self._ps_side = []                  # side streams of the per-step parts, created on first use
         self._ps_unjoined = False           # run(..., join=False) left work on the side streams the caller's has not waited for
         self._R0 = None if R0 is None else np.asarray(R0, dtype=np.float64).reshape(SP, N)
@@ -532,6 +533,9 @@ class EnsembleEngine:
                 k = self.auto_k_steps() if k_steps is None else int(k_steps)
                 fn = getattr(self.lib, f"fiveeq_run_ksteps_{self._sfx}")
                 rc = fn(*self._run_args(t_begin, t_end), max(k, 1), self._stream(stream))
+            elif mode == "small":
+                fn = getattr(self.lib, f"fiveeq_run_small_{self._sfx}")
+                rc = fn(*self._run_args(t_begin, t_end)[:-1], int(self.small_lanes), self._stream(stream))
             elif mode == "tiled":
                 fn = getattr(self.lib, f"fiveeq_run_tiled_{self._sfx}")
                 lo_h, hi_h, nb = self.hist_spec if self.hist_spec is not None else (0.0, 1.0, 0)
