@@ -24,14 +24,18 @@ repeated back to back for --timed-s (6.5) seconds of device time, HIP event to H
 enqueuing at once.  `roofline` prices the kernel of the chosen --mode: the per-step kernel against the
 8 TB/s HBM peak with the ALGORITHMIC bytes A = w(2 SP + 4 G + 7) = 248 B per member-step (plus the same
 kernel on an ensemble far beyond the Infinity Cache, `hbm_resident`, and its fp64 VALU issue fraction);
-the fused / K-step kernels with their own A and bound "fp64-valu".  `cpu_baseline` times the CPU oracle
+the fused / K-step / small-ensemble kernels with their own A and bound "fp64-valu"; `roofline.single_launch_*` is the per-step
+kernel as ONE launch per timestep on one stream (north_star's literal shape) beside the default two-launch form.  `cpu_baseline` times the CPU oracle
 (NumPy, one process per usable core, and the plain-C port under OpenMP) on this box's host cores on a bounded sample
 (rank 0, N=1 only) BEFORE the GPU is touched, so that the GPU work of the run is one contiguous window.
 
 With N > 1 and no explicit --mode the per-step form falls back to its hipGraph replay (same kernels, same bits) when the slowest
 rank's host thread needs more than --host-share-limit (0.5) of a step to enqueue it: `config.mode`, `timing.host_fallback`.
 
-N > 1: one process per GPU; time-stepping needs no collective.  The barriers around the clocked region and the MAX of the
+N > 1: one process per GPU; time-stepping needs no collective.  The line proves what ran: `config.devices` (every rank's device
+index, name, PCI bus id, uuid), `timing.per_rank_ms_per_step`, `timing.per_rank_host_enqueue_us` — gathered over the control
+plane, so they survive an RCCL failure — and, inside the protected summary section, `summary.rccl_world_size` /
+`summary.backend_seen` as the data group itself reports them after its first collective, and the bytes every rank sent the root.  The barriers around the clocked region and the MAX of the
 clocked times go over a gloo control group (host scalars); the end-of-run summary exchange — the only collective that moves
 ensemble data — goes over RCCL, LAST, with the line already complete and a watchdog thread beside it: a failed or hung
 exchange costs the line its `summary` (-> {"error": ...}, non-zero exit), never its measurement.
@@ -152,11 +156,11 @@ def parse():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--members", type=int, default=0, help="members per GPU (default: the workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--mode", default=None, choices=["per_step", "graph", "fused", "ksteps", "auto", "tiled"],
+    ap.add_argument("--mode", default=None, choices=["per_step", "graph", "fused", "ksteps", "small", "auto"],
                     help="default: per_step — and, for N > 1 only, its hipGraph replay (same kernels, same bits) if the host "
                          "thread of the slowest rank needs more than --host-share-limit of a step to enqueue it")
     ap.add_argument("--host-share-limit", type=float, default=0.5)
-    ap.add_argument("--k-steps", type=int, default=0, help="steps per launch for --mode ksteps/tiled (0: the engine's choice)")
+    ap.add_argument("--k-steps", type=int, default=0, help="steps per launch for --mode ksteps (0: the engine's choice)")
     ap.add_argument("--no-trajectory", action="store_true", help="do not store C/T rows (drops G+1 writes from A)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the beyond-Infinity-Cache roofline leg")
@@ -441,6 +445,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return [float(v) for v in tt.tolist()]
 
+    def gather_over_ranks(obj):
+        """Every rank's (small, picklable) `obj` as a list indexed by rank, on every rank — over the control plane."""
+        if dist is None:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    props = torch.cuda.get_device_properties(dev)
+    devices = gather_over_ranks({"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": props.name,
+                                 "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                                                   getattr(props, "pci_device_id", 0)),
+                                 "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
+                                 "visible_devices": torch.cuda.device_count()})
+
     # ---- device spin-up (not model work): the GPU idles at its lowest clock during host set-up;
     # ~30 ms of a plain copy kernel brings it back so that a small W is enough ----
     spin_src = torch.empty(1 << 25, dtype=torch.float64, device=dev).normal_()
@@ -498,6 +517,7 @@ def main():
             e1.synchronize()
             dev_t.append(e0.elapsed_time(e1) * 1e-3 / k_burst)
         torch.cuda.synchronize(dev)
+        host_enqueue.mine = float(np.median(enq))            # this rank's own figure (gathered per rank for the line)
         med, mn, dmed = max_over_ranks([float(np.median(enq)), float(np.min(enq)), float(np.median(dev_t))])
         return med, mn, dmed, t_from
 
@@ -584,12 +604,17 @@ def main():
             est = float(np.median(max_over_ranks(probe)))
         repeats = int(min(max(a.max_repeats, 1), -(-a.timed_s // max(est, 1e-6)))) | 1     # odd
         blocks, wall_all, t_idx = clock_blocks(repeats, t_idx)
+    per_rank_ms_per_step = gather_over_ranks(float(np.median(blocks)) / a.steps * 1e3)      # each rank's own median block
     blocks = max_over_ranks(blocks)                              # per block: the slowest rank
     elapsed = float(np.median(blocks))
     value = n_total * a.steps / elapsed
 
     enq_med, enq_min, _, t_idx = host_enqueue(a.mode, t_idx)
-    timing = {"timed_repeats": repeats, "block_ms_min_median_max": [min(blocks) * 1e3, elapsed * 1e3, max(blocks) * 1e3],
+    per_rank_enq_us = gather_over_ranks(host_enqueue.mine * 1e6)
+    timing = {"timed_repeats": repeats,
+              "per_rank_ms_per_step": per_rank_ms_per_step, "per_rank_host_enqueue_us": per_rank_enq_us,
+              "per_rank_is": "rank r's own median block / K, and its own median enqueue time per step (list index = rank); "
+                             "`ms_per_step` is the median over blocks of the per-block MAX over ranks", "block_ms_min_median_max": [min(blocks) * 1e3, elapsed * 1e3, max(blocks) * 1e3],
               "device_s_clocked": float(np.sum(blocks)),
               "first_block_ms_per_step": first_max / a.steps * 1e3,
               "first_block_is": "ONE K-step block on the wall clock (barrier, device sync, clock, K steps, drained stream, "
@@ -633,7 +658,8 @@ def main():
     vtag = a.dtype + ("x2" if packed else "")
     members_per_wave = 128 if packed else 64
     pools3 = ",".join(str(x) for x in (eng.pools + [0, 0])[:3])
-    fusedlike = a.mode in ("fused", "ksteps", "tiled") or (a.mode == "auto" and eng.auto_k_steps() > 1)
+    mode_run = eng.resolve_mode(a.mode, k_steps)[0]              # what --mode auto resolves to on this ensemble
+    fusedlike = mode_run in ("fused", "ksteps", "small")
     if not fusedlike:
         A = eng.bytes_per_member_step("per_step")
         # One timestep = n_seq member chunks one after the other (chunk-major schedule of large ensembles) x `conc` parts of
@@ -684,18 +710,37 @@ def main():
                     "achieved_per_launch": A * members_per_launch / k_avg / 1e9,
                     "avg_launch_us": k_avg * 1e6, "min_launch_us": float(samples.min()) * 1e6,
                     "launches_timed": int(samples.size) * per_batch * n_launch, "note": note}
+        # north_star's literal launch shape — ONE kernel per timestep, one stream — beside the default above (from ~0.5M members
+        # the engine runs a timestep as two launches over member halves on two streams: a measured -5...-8 %, same bits)
+        if conc > 1 and n_seq == 1:
+            eng.join()
+            saved_streams, eng.per_step_streams = eng.per_step_streams, 1
+            one = event_timed(eng, lambda t0_, t1_: eng.run(t0_, t1_, mode="per_step", join=False), t_idx, n_scen, per_batch,
+                              a.kernel_batches, lanes=eng.per_step_stream_list()) / per_batch
+            eng.per_step_streams = saved_streams
+            k_one = float(one.mean())
+        else:
+            k_one = k_avg                                       # the default already is one launch per timestep (and chunk)
+        ach_one = A * members_per_launch * conc / k_one / 1e9
+        roofline["single_launch"] = {"avg_launch_us": k_one * 1e6, "achieved": ach_one, "frac": ach_one / HBM_PEAK_GBS,
+                                     "members_per_launch": members_per_launch * conc,
+                                     "is": "the same kernel as ONE launch per timestep on one stream (per_step_streams=1), "
+                                           "100-launch HIP-event batches like avg_launch_us"}
+        roofline["single_launch_avg_us"], roofline["single_launch_achieved"] = k_one * 1e6, ach_one
+        roofline["single_launch_frac"] = ach_one / HBM_PEAK_GBS
         kkey = f"step:{vtag}:{pools3}"
     else:
         # the time-fused family: one launch covers `span` steps; price it per step with its own A
-        if a.mode == "tiled":
-            span = k_steps or eng.tile_steps()
-            kname, mode_t = "tile_kernel", "tiled"
-        elif a.mode == "fused":
+        if mode_run == "small":
+            lpm = eng.small_form()
+            span, kname, mode_t = n_scen, "small_kernel", "small"
+            lname, vtag, members_per_wave = f"{tname},{eng.pools[0]},{lpm}", a.dtype, 64 // lpm      # (never packed)
+        elif mode_run == "fused":
             span, kname, mode_t = eng.fused_span_steps(n_scen), "fused_kernel", "fused"     # the engine relaunches small ensembles
         else:
             span = k_steps or eng.auto_k_steps()
             kname, mode_t = "fused_kernel", "ksteps"
-        A = eng.bytes_per_member_step("fused" if a.mode == "fused" else mode_t, None if a.mode == "fused" else span)
+        A = eng.bytes_per_member_step(mode_t, span if mode_t == "ksteps" else None)
         # Timed the way the timed region runs it: whole scenario passes from the initial state (HIP events on the
         # launch stream around each pass; the launches of a pass are enqueued back-to-back from C).
         samples = []
@@ -703,7 +748,7 @@ def main():
             eng.reset_state()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            eng.run(0, n_scen, mode=mode_t, k_steps=None if a.mode == "fused" else span)
+            eng.run(0, n_scen, mode=mode_t, k_steps=span if mode_t == "ksteps" else None)
             e1.record()
             e1.synchronize()
             samples.append(e0.elapsed_time(e1) * 1e-3 / n_scen)
@@ -711,19 +756,24 @@ def main():
         reps = -(-n_scen // span)
         k_avg = float(samples.mean())                           # seconds per model step inside the kernel
         achieved = A * n_local / k_avg / 1e9
+        kernel_name = (f"fiveeq::small_kernel<{lname}>" if kname == "small_kernel" else f"fiveeq::{kname}<{lname},{pools3}>")
         roofline = {"bound": "fp64-valu" if a.dtype == "f64" else "fp32-valu", "unit": "wave-instr/s",
                     "achieved": None, "peak": valu_peak, "frac": None, "traffic": None,
-                    "kernel": f"fiveeq::{kname}<{lname},{pools3}>", "steps_per_launch": span,
+                    "kernel": kernel_name, "steps_per_launch": span,
                     "algorithmic_bytes_per_member_step": A, "members_per_launch": n_local,
                     "hbm_GBs_of_algorithmic_bytes": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
                     "avg_step_us_in_kernel": k_avg * 1e6, "launches_timed": int(samples.size) * reps,
                     "timed_as": f"{samples.size} whole {n_scen}-step scenario passes from the initial state",
                     "note": "time-fused family: state stays in registers, the kernel is bound by VALU issue, not HBM; "
                             "frac = VALU wave-instructions per second / (1024 SIMDs x 2.4 GHz / cycles per instruction)."}
-        kkey = f"{'fused' if kname == 'fused_kernel' else 'tile'}:{vtag}:{pools3}"      # the tiled kernel packs its fp32 lanes too
-        if kname == "tile_kernel":
-            roofline["note"] += ("  The tiled kernel's instruction count in profiles/valu.json was taken WITH its 4096-bin in-loop "
-                                 "histogram at 8 steps per tile: without the histogram, or with longer tiles, it executes fewer.")
+        if kname == "small_kernel":
+            waves_ = -(-n_local // members_per_wave)
+            roofline["lanes_per_member"], roofline["waves"] = lpm, waves_
+            roofline["note"] = (f"small-ensemble kernel: {lpm} lane(s) per member, {waves_} waves for {SIMDS} SIMDs — a wave alone on "
+                                "its SIMD issues one vector instruction per ~3.7-4.2 ns whatever the instruction, so the run is bound "
+                                "by the instructions ONE wave issues per step (valu_issue.valu_wave_instr_per_wave_step), not by the "
+                                "chip's VALU peak: frac prices the waves that exist against all 1024 SIMDs at nominal issue.")
+        kkey = (f"small:{vtag}:{pools3}:{lpm}" if kname == "small_kernel" else f"fused:{vtag}:{pools3}")
     # VALU issue: instructions per wave-step from the committed SQ-counter pass (profiles/valu.json, produced by
     # tools/collect_profiles.sh with rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ...), times the waves this bench ran
     valu = load_profile_json("valu.json", kkey)
@@ -805,6 +855,11 @@ def main():
         big.close()
         del big, pb
 
+    first = ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_resident_frac", "single_launch_frac",
+             "single_launch_avg_us", "frac_of_stream_copy", "avg_launch_us", "kernel", "algorithmic_bytes_per_member_step",
+             "members_per_launch", "concurrent_launches", "fp64_issue_frac", "fp32_issue_frac", "stream_copy_GBs",
+             "stream_copy_16B_per_lane_GBs")
+    roofline = {**{k: roofline[k] for k in first if k in roofline}, **{k: v for k, v in roofline.items() if k not in first}}
     out = {
         "metric": "ensemble_member_timesteps_per_sec", "value": value, "unit": "member-timesteps/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -812,7 +867,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
         "data": "synthetic",
         "config": {"workload": f"{a.workload}: {desc}", "members_per_gpu": per_gpu, "members_total": n_total,
-                   "gases": G, "pools": eng.pools, "scenario_steps": n_scen, "mode": a.mode,
+                   "gases": G, "pools": eng.pools, "scenario_steps": n_scen, "mode": a.mode, "mode_resolved": mode_run,
                    "mode_requested": mode_requested or "default",
                    "steps_per_launch": (roofline.get("steps_per_launch", 1)),
                    "trajectory_stored": eng.C is not None, "parallelism": f"member-shard x{world}",
@@ -821,7 +876,8 @@ def main():
                    "control_plane": None if dist is None else "gloo over 127.0.0.1 (barriers, MAX of the clocked times)",
                    "emissions_sha256": emissions.emissions_sha256(E)[:16], "lhs_seed": params.LHS_SEED,
                    "lhs_design": "shard-computable (keyed Feistel bijection), drawn on the device",
-                   "setup_s_rank0": setup_s},
+                   "setup_s_rank0": setup_s,
+                   "devices": devices},
         "roofline": roofline,
     }
     if cpu is not None:
@@ -872,9 +928,13 @@ def main():
             summary_ms = (time.perf_counter() - ts) * 1e3
             if watchdog is not None:
                 watchdog.cancel()
+            seen = {"rccl_world_size": None, "backend_seen": None}
+            if dist is not None:               # as the DATA group reports them, after its first collectives have run
+                seen = {"rccl_world_size": dist.get_world_size(data_group), "backend_seen": dist.get_backend(data_group)}
             if rank == 0:
-                emit({"years": years, "gather_ms": summary_ms, "gather_ms_is": "second (warm) call",
+                emit({"years": years, "gather_ms": summary_ms, "gather_ms_is": "second (warm) call", **seen,
                       "bytes_to_root": summary_stats.get("bytes_to_root"),
+                      "bytes_to_root_per_rank": summary_stats.get("bytes_to_root_per_rank"),
                       "allreduce_bytes": summary_stats.get("allreduce_bytes"),
                       "T_mean": [float(x) for x in summ["mean"]],
                       "T_p05_p50_p95": [[float(v) for v in row] for row in summ["percentiles"]]})

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FIVEEQ_LIB_PATH selects another build of the same library (e.g. the host-sanitizer build of tools/sanitize_host.sh)
 LIB_PATH = os.environ.get("FIVEEQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_GAS = 3
 MAX_POOLS = 4
 N_BOX = 2
@@ -96,13 +96,7 @@ SIGNATURES = {
     "fiveeq_run_small_f64": (ctypes.c_int, _RUN_ARGS[:-2] + [_i32, _p]),
     "fiveeq_run_small_f32": (ctypes.c_int, _RUN_ARGS[:-2] + [_i32, _p]),
     "fiveeq_small_lanes": (_i32, [_i32, ctypes.POINTER(_i32)]),
-    "fiveeq_run_tiled_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
-    "fiveeq_run_tiled_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
-    "fiveeq_tile_steps_f64": (_i32, [_i32]),
-    "fiveeq_tile_steps_f32": (_i32, [_i32]),
     "fiveeq_set_f32_packing": (ctypes.c_int, [ctypes.c_int]),
-    "fiveeq_tile_lds_bytes": (_i32, []),
-    "fiveeq_tile_attr_calls": (_i32, []),
     "fiveeq_lhs_rows_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p, _p]),
     "fiveeq_lhs_rows_host_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p]),
     "fiveeq_plan_launch": (ctypes.c_int, [_p, _p]),
@@ -110,9 +104,6 @@ SIGNATURES = {
     "fiveeq_hfc_conc_f64": (ctypes.c_int, [_i64, _i64, _i32, _p, _p, _p, _p]),
     "fiveeq_hist_rows_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
     "fiveeq_hist_rows_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p]),
-    "fiveeq_hist_rows_stats_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p, _p]),
-    "fiveeq_hist_rows_stats_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, ctypes.c_double, ctypes.c_double, _i32, _p, _p, _p]),
-    "fiveeq_hist_rows_chunks": (ctypes.c_int64, [_i32, _i64]),
     "fiveeq_row_moments_chunks": (ctypes.c_int64, [_i32, _i64]),
     "fiveeq_row_moments_f64": (ctypes.c_int, [_i32, _i64, _i64, _p, _p, _p, _p]),
     "fiveeq_row_moments_f32": (ctypes.c_int, [_i32, _i64, _i64, _p, _p, _p, _p]),
@@ -185,6 +176,11 @@ def load(path=None):
     if want is not None and got_hash != want and os.environ.get("FIVEEQ_ALLOW_STALE_LIB") != "1":
         raise ImportError(f"{lib_path} was built from other sources (library {got_hash[:16]}, tree {want[:16]}): "
                           "run `make -C fiveeqscm_amd/csrc`")
+    # ... and it must be the PRODUCT build: a variant compiled with experiment knobs (csrc/Makefile EXTRA=-D...) carries the same
+    # source hash, and only fiveeq_build_flags() tells it apart
+    flags = (lib.fiveeq_build_flags() or b"").decode().strip()
+    if flags and os.environ.get("FIVEEQ_ALLOW_STALE_LIB") != "1":
+        raise ImportError(f"{lib_path} is an experiment build ({flags}); set FIVEEQ_ALLOW_STALE_LIB=1 to load it (tools/ only)")
     if path is None:
         _lib = lib
     return lib

@@ -4,6 +4,7 @@
 #include "fiveeq.h"
 #include "fiveeq_device.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -148,6 +149,7 @@ struct RunArgs {
     int n_rows;
     int n_steps;
     double* stats;
+    int packing;                 // the fp32 packing switch as this call found it
 };
 
 // the bin-index ring of the streamed histograms (fused_kernel<..., BINS = true>)
@@ -163,7 +165,9 @@ struct BinRing {
 // pointer 8-byte aligned, at least two members.  Otherwise (odd ld, a sub-range starting at an odd member) the
 // one-member-per-lane kernels run; both give the same bits.  fiveeq_set_f32_packing(0) forces the scalar kernels (A/B
 // measurements, and the tests that compare the two).
-int g_f32_packing = 1;
+// Process-wide and changeable at any time from any thread: a relaxed atomic, read ONCE per C-ABI call (make_args), so that
+// every launch of one call takes the same kernel shape.
+std::atomic<int> g_f32_packing{1};
 
 template <typename T>
 struct LaneOf {
@@ -174,7 +178,7 @@ template <>
 struct LaneOf<float> {
     using Packed = float2v;
     static bool can_pack(const RunArgs<float>& a) {
-        if (!g_f32_packing || a.n < 2 || (a.ld & 1)) return false;
+        if (!a.packing || a.n < 2 || (a.ld & 1)) return false;
         const uintptr_t bits = (uintptr_t)a.r | (uintptr_t)a.q | (uintptr_t)a.R | (uintptr_t)a.S | (uintptr_t)a.C_traj |
                                (uintptr_t)a.T_traj;
         return (bits & 7u) == 0;
@@ -263,6 +267,7 @@ int make_args(RunArgs<T>& a, const fiveeq_model* m, int64_t n, int64_t ld, const
     a.n_rows = n_rows;
     a.n_steps = n_steps;
     a.stats = stats;
+    a.packing = g_f32_packing.load(std::memory_order_relaxed);
     return FIVEEQ_OK;
 }
 
@@ -380,143 +385,6 @@ int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     return FIVEEQ_OK;
 }
 
-// ---- time-tiled persistent kernel with in-loop histograms ---------------------------------------
-// LDS a workgroup may use, from the device (hipDeviceAttributeMaxSharedMemoryPerBlock: 160 KiB on MI355X), asked once per
-// thread and device.  Without a device (the CPU build container, where only the argument checks run) the gfx950 figure is
-// assumed, so that fiveeq_tile_steps_* answers the same there.
-constexpr int GFX950_LDS_BYTES = 160 * 1024;
-struct DeviceFacts {
-    int dev = -1, cus = 256, lds_bytes = GFX950_LDS_BYTES;
-};
-const DeviceFacts& device_facts() {
-    static thread_local DeviceFacts f;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) {
-        (void)hipGetLastError();
-        return f;                                           // no device: defaults (or the last device's facts)
-    }
-    if (dev != f.dev) {
-        int v = 0;
-        f.cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-        f.lds_bytes = (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
-                          ? v : GFX950_LDS_BYTES;
-        f.dev = dev;
-    }
-    return f;
-}
-int device_cus() { return device_facts().cus; }
-int device_lds_bytes() { return device_facts().lds_bytes; }
-
-// static LDS of tile_kernel<V>: drive records + the statistics tiles (one lane VALUE per slot: 8 bytes for fp64 and for
-// the packed fp32 lanes, 4 for scalar fp32) + the staged model.  The fp32 entry points may run either the packed or the
-// scalar instantiation, so the tile size they advertise is the packed kernel's (the larger tile, the smaller K).
-template <typename T>
-constexpr int tile_static_lds() {
-    constexpr int lane_bytes = 8;                          // double, or float2v
-    return (int)(sizeof(T) * TILE_MAX_STEPS * DRIVE_STRIDE + lane_bytes * (TILE_BLOCK / 64) * STAT_STEPS * STAT_ROW +
-                 sizeof(KModel<T>) + 8 /* the work-item counter, padded to a lane */);
-}
-// largest K whose histogram [K][ceil(n_bins/2)] dwords fits beside the kernel's static LDS
-template <typename T>
-int tile_steps_max(int n_bins) {
-    if (n_bins < 1) return TILE_MAX_STEPS;
-    const int hw_bytes = ((n_bins + 1) / 2) * 4;
-    const int k = (device_lds_bytes() - tile_static_lds<T>() - 512) / hw_bytes;
-    return k > TILE_MAX_STEPS ? TILE_MAX_STEPS : k;
-}
-
-// A launch with more than 48 KiB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize raised on the kernel
-// first.  That is a property of (kernel instantiation, device), not of a launch: it is set ONCE per instantiation and
-// device, to the largest size this build can ask for (the device's LDS minus the kernel's static part), and remembered.
-int g_tile_attr_calls = 0;                                  // how often the attribute was really set (tests)
-template <typename T>
-int tile_prepare(int code, size_t dyn_needed) {
-    if (dyn_needed <= 48 * 1024) return FIVEEQ_OK;
-    static thread_local int done_dev[1000];                 // by layout code p0*100 + p1*10 + p2: device + 1 it is set for
-    const int dev = device_facts().dev;
-    if (code < 0 || code >= 1000) return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", code);
-    if (done_dev[code] == dev + 1) return FIVEEQ_OK;
-    const int dyn_max = device_lds_bytes() - tile_static_lds<T>();
-    using P = typename LaneOf<T>::Packed;
-    switch (code) {
-#define X(p0, p1, p2)                                                                                        \
-    case (p0) * 100 + (p1) * 10 + (p2):                                                                      \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<T, p0, p1, p2>),               \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));                   \
-        if (!std::is_same<P, T>::value)                                                                      \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<P, p0, p1, p2>),           \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max));               \
-        break;
-        FIVEEQ_LAYOUTS(X)
-#undef X
-        default:
-            return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", code);
-    }
-    ++g_tile_attr_calls;
-    done_dev[code] = dev + 1;
-    return FIVEEQ_OK;
-}
-
-template <typename T>
-int launch_tile(const RunArgs<T>& a, int t_begin, int t_end, double lo, double inv_w, int n_bins,
-                unsigned long long* hist, hipStream_t st) {
-    using P = typename LaneOf<T>::Packed;
-    const bool packed = LaneOf<T>::can_pack(a);
-    const int64_t per_block = (int64_t)TILE_BLOCK * (packed ? 2 : 1);
-    const int64_t n_blocks = (a.n + per_block - 1) / per_block;
-    const int cus = device_cus();
-    const int64_t wgs = (int64_t)cus * (1024 / TILE_BLOCK);
-    const dim3 grid((unsigned)(n_blocks < wgs ? n_blocks : wgs)), block(TILE_BLOCK);
-    const size_t dyn = hist ? (size_t)(t_end - t_begin) * ((n_bins + 1) / 2) * 4 : 0;
-    switch (a.code) {
-#define X(p0, p1, p2)                                                                                        \
-    case (p0) * 100 + (p1) * 10 + (p2):                                                                      \
-        if (packed)                                                                                          \
-            hipLaunchKernelGGL((tile_kernel<P, p0, p1, p2>), grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, \
-                               a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, \
-                               hist);                                                               \
-        else                                                                                                 \
-            hipLaunchKernelGGL((tile_kernel<T, p0, p1, p2>), grid, block, dyn, st, a.km, a.drive, a.n_steps, t_begin, t_end, \
-                               a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, lo, inv_w, n_bins, \
-                               hist);                                                               \
-        break;
-        FIVEEQ_LAYOUTS(X)
-#undef X
-        default:
-            return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
-    }
-    HIP_TRY(hipGetLastError());
-    return FIVEEQ_OK;
-}
-
-template <typename T>
-int run_tiled(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
-              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats,
-              int32_t k_steps, double lo, double hi, int32_t n_bins, uint64_t* hist, void* stream) {
-    RunArgs<T> a;
-    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
-    double inv_w = 0.0;
-    if (hist) {
-        if (n_bins < 1 || n_bins > HIST_MAX_BINS)
-            return fail(FIVEEQ_E_INVALID, "n_bins=%d outside 1..%d", n_bins, HIST_MAX_BINS);
-        if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) return fail(FIVEEQ_E_INVALID, "need finite lo < hi");
-        inv_w = (double)n_bins / (hi - lo);
-    } else {
-        n_bins = 0;
-    }
-    const int k_max = tile_steps_max<T>(n_bins);
-    if (k_max < 1) return fail(FIVEEQ_E_INVALID, "n_bins=%d leaves no LDS for one step", n_bins);
-    if (k_steps < 0 || k_steps > k_max)
-        return fail(FIVEEQ_E_INVALID, "k_steps=%d outside 0..%d (0 = largest that fits)", k_steps, k_max);
-    if (k_steps == 0) k_steps = k_max;
-    if (int rc = tile_prepare<T>(a.code, (size_t)k_max * ((n_bins + 1) / 2) * 4)) return rc;
-    for (int t = t_begin; t < t_end; t += k_steps)
-        if (int rc = launch_tile<T>(a, t, t + k_steps < t_end ? t + k_steps : t_end, lo, inv_w, n_bins,
-                                    reinterpret_cast<unsigned long long*>(hist), (hipStream_t)stream))
-            return rc;
-    return FIVEEQ_OK;
-}
-
 // ---- plans: the per-step launch sequence captured into a hipGraph --------------------------
 struct Plan {
     uint32_t magic;
@@ -583,9 +451,6 @@ const char* fiveeq_build_flags(void) {
 #ifdef FIVEEQ_FUSED_TIMING
            " FIVEEQ_FUSED_TIMING"
 #endif
-#ifdef FIVEEQ_TILE_TIMING
-           " FIVEEQ_TILE_TIMING"
-#endif
 #ifdef FIVEEQ_STEP_WAVES
            " FIVEEQ_STEP_WAVES=" FIVEEQ_STR(FIVEEQ_STEP_WAVES)
 #endif
@@ -600,9 +465,6 @@ const char* fiveeq_build_flags(void) {
 #endif
 #if FIVEEQ_STEP_BLOCK != 64
            " FIVEEQ_STEP_BLOCK=" FIVEEQ_STR(FIVEEQ_STEP_BLOCK)
-#endif
-#if FIVEEQ_TILE_BLOCK != 1024
-           " FIVEEQ_TILE_BLOCK=" FIVEEQ_STR(FIVEEQ_TILE_BLOCK)
 #endif
 #ifdef FIVEEQ_BIN_RULE_F64
            " FIVEEQ_BIN_RULE_F64"
@@ -732,20 +594,6 @@ int fiveeq_run_ksteps_f32(const fiveeq_model* model, int64_t n_members, int64_t 
     return run_ksteps<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
                              T_stats, k_steps, stream);
 }
-int fiveeq_run_tiled_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
-                         int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
-                         double* S, double* C_traj, double* T_traj, int32_t n_rows, double* T_stats, int32_t k_steps,
-                         double hist_lo, double hist_hi, int32_t n_bins, uint64_t* T_hist, void* stream) {
-    return run_tiled<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
-                             T_stats, k_steps, hist_lo, hist_hi, n_bins, T_hist, stream);
-}
-int fiveeq_run_tiled_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
-                         int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
-                         float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, int32_t k_steps,
-                         double hist_lo, double hist_hi, int32_t n_bins, uint64_t* T_hist, void* stream) {
-    return run_tiled<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
-                            T_stats, k_steps, hist_lo, hist_hi, n_bins, T_hist, stream);
-}
 int fiveeq_run_small_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
                          int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
                          double* S, double* C_traj, double* T_traj, int32_t n_rows, int32_t lanes_per_member, void* stream) {
@@ -764,15 +612,7 @@ int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t* n_pools) {
     for (int g = 0; g < n_gas; ++g) p[g] = n_pools[g];
     return small_lanes(p[0] * 100 + p[1] * 10 + p[2]);
 }
-int fiveeq_set_f32_packing(int on) {
-    const int prev = g_f32_packing;
-    g_f32_packing = on ? 1 : 0;
-    return prev;
-}
-int32_t fiveeq_tile_lds_bytes(void) { return device_lds_bytes(); }
-int32_t fiveeq_tile_attr_calls(void) { return g_tile_attr_calls; }
-int32_t fiveeq_tile_steps_f64(int32_t n_bins) { return n_bins < 0 || n_bins > fiveeq::HIST_MAX_BINS ? 0 : tile_steps_max<double>(n_bins); }
-int32_t fiveeq_tile_steps_f32(int32_t n_bins) { return n_bins < 0 || n_bins > fiveeq::HIST_MAX_BINS ? 0 : tile_steps_max<float>(n_bins); }
+int fiveeq_set_f32_packing(int on) { return g_f32_packing.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 
 static int lhs_check(int64_t n_total, int64_t m0, int64_t n_members, int32_t dim0, int32_t n_dim, int64_t ld) {
     // 2^28: stratum (28 bits) + the 24-bit jitter placed mid-cell (25 fractional bits) is then an EXACT fp64 sum, so u lies
@@ -891,7 +731,7 @@ int64_t hist_chunk(int32_t n_rows, int64_t n) {
 
 template <typename T>
 int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, double hi, int32_t n_bins,
-              uint64_t* hist, double* moments, void* stream, const double* ranges = nullptr) {
+              uint64_t* hist, void* stream, const double* ranges = nullptr) {
     if (n_rows < 0) return fail(FIVEEQ_E_INVALID, "n_rows=%d must be >= 0", n_rows);
     if (n < 1 || ld < n) return fail(FIVEEQ_E_INVALID, "n_members=%lld, ld=%lld invalid", (long long)n, (long long)ld);
     if (n_bins < 1 || n_bins > fiveeq::HIST_MAX_BINS)
@@ -904,22 +744,16 @@ int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, d
     if (ranges) {
         // the summary's histogram (a few rows): every workgroup zeroes and flushes all n_bins counters, which at 2048 workgroups
         // of 18k members each is a third of the pass (68 us for 3 x 12.5M fp32 values at 4096 bins, 40 at 1024 bins) — at least
-        // 8 members per bin and workgroup: 47 us.  (The ring passes count 64+ rows per launch and are far beyond that already;
-        // the entry points with moments keep the chunking fiveeq_hist_rows_chunks advertises.)
+        // 8 members per bin and workgroup: 47 us.  (The ring passes count 64+ rows per launch and are far beyond that already.)
         const int64_t floor_ = (8LL * n_bins + FIVEEQ_BLOCK - 1) / FIVEEQ_BLOCK * FIVEEQ_BLOCK;
         if (chunk < floor_) chunk = floor_;
     }
     const int64_t chunks = (n + chunk - 1) / chunk;
     if (chunks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large");
     const double inv_w = ranges ? 0.0 : (double)n_bins / (hi - lo);
-    if (moments)
-        hipLaunchKernelGGL((fiveeq::hist_rows_kernel<T, true>), dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
-                           (hipStream_t)stream, n, ld, chunk, rows, lo, inv_w, n_bins,
-                           reinterpret_cast<unsigned long long*>(hist), moments, ranges);
-    else
-        hipLaunchKernelGGL((fiveeq::hist_rows_kernel<T, false>), dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
-                           (hipStream_t)stream, n, ld, chunk, rows, lo, inv_w, n_bins,
-                           reinterpret_cast<unsigned long long*>(hist), moments, ranges);
+    hipLaunchKernelGGL(fiveeq::hist_rows_kernel<T>, dim3((unsigned)chunks, (unsigned)n_rows), dim3(FIVEEQ_BLOCK), 0,
+                       (hipStream_t)stream, n, ld, chunk, rows, lo, inv_w, n_bins, reinterpret_cast<unsigned long long*>(hist),
+                       ranges);
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;
 }
@@ -943,22 +777,7 @@ int math_probe(int32_t op, int64_t n, const T* x, T* y, void* stream) {
 extern "C" {
 int fiveeq_hist_rows_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, double lo, double hi,
                          int32_t n_bins, uint64_t* hist, void* stream) {
-    return hist_rows<double>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, nullptr, stream);
-}
-int fiveeq_hist_rows_stats_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, double lo, double hi,
-                               int32_t n_bins, uint64_t* hist, double* moments, void* stream) {
-    if (!moments) return fail(FIVEEQ_E_INVALID, "moments is NULL");
-    return hist_rows<double>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, moments, stream);
-}
-int fiveeq_hist_rows_stats_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, double lo, double hi,
-                               int32_t n_bins, uint64_t* hist, double* moments, void* stream) {
-    if (!moments) return fail(FIVEEQ_E_INVALID, "moments is NULL");
-    return hist_rows<float>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, moments, stream);
-}
-int64_t fiveeq_hist_rows_chunks(int32_t n_rows, int64_t n_members) {
-    if (n_rows < 1 || n_members < 1) return 0;
-    const int64_t chunk = hist_chunk(n_rows, n_members);
-    return (n_members + chunk - 1) / chunk;
+    return hist_rows<double>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, stream);
 }
 int fiveeq_hist_bins(int32_t n_rows, int64_t n_members, int64_t ld, const uint16_t* bins, int32_t n_bins, uint64_t* hist,
                      void* stream) {
@@ -981,7 +800,7 @@ int fiveeq_hist_bins(int32_t n_rows, int64_t n_members, int64_t ld, const uint16
 }
 int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, double lo, double hi,
                          int32_t n_bins, uint64_t* hist, void* stream) {
-    return hist_rows<float>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, nullptr, stream);
+    return hist_rows<float>(n_rows, n_members, ld, rows, lo, hi, n_bins, hist, stream);
 }
 // ---- end-of-run summary passes (kernels 6a-6c) ----------------------------------------------------------------
 }  // extern "C"
@@ -1072,12 +891,12 @@ int fiveeq_row_moments_f32(int32_t n_rows, int64_t n_members, int64_t ld, const 
 int fiveeq_hist_rows_ranged_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, const double* ranges,
                                 int32_t n_bins, uint64_t* hist, void* stream) {
     if (!ranges) return fail(FIVEEQ_E_INVALID, "ranges is NULL");
-    return hist_rows<double>(n_rows, n_members, ld, rows, 0.0, 0.0, n_bins, hist, nullptr, stream, ranges);
+    return hist_rows<double>(n_rows, n_members, ld, rows, 0.0, 0.0, n_bins, hist, stream, ranges);
 }
 int fiveeq_hist_rows_ranged_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float* rows, const double* ranges,
                                 int32_t n_bins, uint64_t* hist, void* stream) {
     if (!ranges) return fail(FIVEEQ_E_INVALID, "ranges is NULL");
-    return hist_rows<float>(n_rows, n_members, ld, rows, 0.0, 0.0, n_bins, hist, nullptr, stream, ranges);
+    return hist_rows<float>(n_rows, n_members, ld, rows, 0.0, 0.0, n_bins, hist, stream, ranges);
 }
 int fiveeq_select_bins_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double* rows, const double* ranges,
                            int32_t n_bins, const uint32_t* binmask, double* cand, int64_t cap, uint64_t* cand_n, void* stream) {

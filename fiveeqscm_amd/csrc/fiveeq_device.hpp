@@ -12,7 +12,7 @@
 // Kernels in this file:
 //   1   step_kernel        one timestep per launch — the north-star form; HBM-bound, A = w(2SP + 4G + 7) per member-step
 //   2   fused_kernel       time-fused (and, INV = true, concentration-driven); state in registers; VALU-bound
-//   2b  tile_kernel        time-tiled, persistent, with the T histogram of every step accumulated in LDS
+//   2c  small_kernel       small ensembles: one member per quad of lanes (pool per lane), the model in registers
 //   3   hfc_conc_kernel    the reference's one function over an ensemble
 //   4   hist_rows_kernel   fixed-bin histograms (+ moments) of rows: the pass of the streamed histogram pipelines
 //   5   lhs_kernel         shard-computable Latin hypercube (keyed Feistel bijection)
@@ -24,7 +24,7 @@
 
 // Floating-point contraction is OFF for this translation unit (here and in csrc/Makefile): the compiler never
 // decides which a*b+c fuse.  Every fused multiply-add of the model step is written as fe_fma() below, so
-// "per-step == fused == tiled == graph bit for bit" and the distance to the CPU oracle are properties of this
+// "per-step == fused == K-step == small == graph bit for bit" and the distance to the CPU oracle are properties of this
 // source, not of a hipcc release.
 #pragma clang fp contract(off)
 
@@ -44,18 +44,14 @@
 #endif
 
 // Experiment hooks (wave / workgroup timestamps): empty in the product.  The code behind them lives in
-// tools/variants/fiveeq_timing_hooks.hpp and is compiled in only by -DFIVEEQ_FUSED_TIMING / -DFIVEEQ_TILE_TIMING builds,
+// tools/variants/fiveeq_timing_hooks.hpp and is compiled in only by -DFIVEEQ_FUSED_TIMING builds,
 // which fiveeq_build_flags() reports (tests/test_capi_cpu.py asserts the shipped library has none).
-#if defined(FIVEEQ_FUSED_TIMING) || defined(FIVEEQ_TILE_TIMING)
+#ifdef FIVEEQ_FUSED_TIMING
 #include "../../tools/variants/fiveeq_timing_hooks.hpp"
 #endif
 #ifndef FIVEEQ_HOOK_FUSED_BEGIN
 #define FIVEEQ_HOOK_FUSED_BEGIN
 #define FIVEEQ_HOOK_FUSED_END
-#endif
-#ifndef FIVEEQ_HOOK_TILE_BEGIN
-#define FIVEEQ_HOOK_TILE_BEGIN
-#define FIVEEQ_HOOK_TILE_END
 #endif
 
 namespace fiveeq {
@@ -733,12 +729,15 @@ __device__ __forceinline__ void wave_stats_flush(const float2v* tile /* [STAT_ST
 // histogram pass (hist_bins_kernel) to count.  The pass no longer sees T, so the moments stay in the kernel (stats).
 constexpr unsigned short BIN_NAN = 0xFFFFu;
 // THE BIN RULE — one definition per row precision, used by every kernel that bins a value (the in-loop forms of the step /
-// fused / tiled kernels, hist_rows_kernel on stored rows, the summary's selection pass), so that "the same counts bit for
+// fused kernels, hist_rows_kernel on stored rows, the summary's selection pass), so that "the same counts bit for
 // bit" between them is a property of this struct.  (lo, inv_w = n_bins / (hi - lo), n_bins) come in as fp64:
 //   fp64 rows:  pos = (v - lo) * inv_w                      in fp64
 //   fp32 rows:  pos = fma(v, (float)inv_w, (float)(-lo * inv_w))    in fp32 — one (packed) FMA where the fp64 form cost ~10
-//               quarter-rate instructions per lane in kernels whose ceiling is VALU issue (round 4); pos < 2^12 carries 12
-//               fractional bits, so a member changes bin against the fp64 form only within 2^-12 of a bin edge
+//               quarter-rate instructions per lane in kernels whose ceiling is VALU issue (round 4).  Against the fp64 form a
+//               member changes bin only within ~2^-23 max(|lo|, |hi|) inv_w of a bin edge (the rounding of scale and offset,
+//               in bins): 2^-12 bin for a range that starts near zero (|lo| inv_w ~ n_bins <= 4096, e.g. temperature
+//               anomalies), more for a range far from zero in units of its own width (lo = 280, hi = 295, 4096 bins: 0.01 bin)
+//               — rows in such absolute units want a range shifted to the anomaly, or fp64 rows
 //   bin = pos clamped to [0, n_bins - 1] and truncated; outliers land in the edge bins; a NaN has no bin (BIN_NAN).
 // Both forms are monotone in v (rounding is), which the summary's selection relies on: members of a lower bin are <= members
 // of a higher one.
@@ -1178,37 +1177,7 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
 }
 
 // ---------------------------------------------------------------------------------
-// Kernel 2b — TIME-TILED, PERSISTENT, with IN-LOOP HISTOGRAMS of T.
-//
-// Why a third shape.  All-timestep percentiles of a 100M-member run need a histogram of T for EVERY
-// step without storing T[n_steps][N].  One global atomic per member-step is out of the question
-// (scattered 64-B atomic requests: ~2e10/s chip-wide against 3e11 member-steps/s), and privatising
-// per workgroup does not help while a workgroup sees only 256 members per step — their T values land
-// in ~256 different bins.  What helps is funnelling MANY members through one LDS histogram for the
-// SAME steps.  So: one launch covers a tile of K = t_end - t_begin steps for ALL members; the grid is
-// one persistent 1024-thread workgroup per CU whose waves work through its member blocks of 1024 lanes
-// (wave items, see below) — load state and parameters, K steps in registers, store state — and keeps
-// hist[K][n_bins] in LDS across all of its
-// blocks (ds_add_u32 on packed 16-bit pairs: 2 bins per dword, so K x 4096 bins = K x 8 KiB).  At the
-// end (or every 63 blocks: 63 x 1024 < 2^16, a 16-bit lane cannot overflow) the non-zero bins go to
-// the global 64-bit counters — consecutive lanes flush consecutive bins, and the occupied bins of a
-// unimodal ensemble are contiguous, so the atomics coalesce.  N/256 members per workgroup against
-// ~1000 occupied bins: 50x fewer global atomics than member-steps at 12.5M members.
-//
-// Per member-step HBM traffic: A_tile = w (2 SP + 4 + 3 G + 2) / K + stored rows + 0.5 B stats
-// (state and parameters once per K steps).  Same member_step(): bit-identical to kernels 1 and 2;
-// the bin formula is hist_rows_kernel's, so the histograms equal those of stored rows bit for bit.
-// ---------------------------------------------------------------------------------
-#ifndef FIVEEQ_TILE_BLOCK
-#define FIVEEQ_TILE_BLOCK 1024
-#endif
-constexpr int TILE_BLOCK = FIVEEQ_TILE_BLOCK;
-constexpr int TILE_MAX_STEPS = 64;
-// blocks a workgroup may histogram before it flushes: a 16-bit lane of the packed LDS counters must not overflow
-template <typename V>
-constexpr int tile_flush_blocks() { return 65535 / (TILE_BLOCK * Lane<V>::W); }      // 63 x 1024 (31 x 2048) <= 65535
-
-// LDS counter increment with ONE round of wave-level aggregation.  In the first decades of a run every member's T sits in a
+// LDS counter increment with ONE round of wave-level aggregation (the histogram passes and the pick pass).  In the first decades of a run every member's T sits in a
 // handful of bins: 64 lanes adding to the same LDS dword serialise (the first two 64-step chunks of a streamed run took
 // 1.9 and 0.8 ms in the histogram pass against 0.35 ms later).
 // So: the wave looks at the counter of its first lane; if at least 16 lanes want that same counter, ONE of them adds their
@@ -1228,170 +1197,6 @@ __device__ __forceinline__ void wave_lds_add(unsigned int* p, const unsigned int
     } else if (key != ~0u) {
         atomicAdd(p, inc);
     }
-}
-
-// count one bin index into the packed 16-bit-pair LDS histogram row.  (Plain LDS atomics here: the aggregation round above
-// costs ~12 VALU instructions per wave-step, which this VALU-bound kernel pays in time — 69.2 -> 69.9-71.6 us/step at the
-// config-5 shard — where the memory-bound passes do not.)
-__device__ __forceinline__ void tile_hist_add(unsigned int* h_row, const unsigned int b) {
-    if (b != (unsigned int)BIN_NAN) atomicAdd(&h_row[b >> 1], (b & 1u) ? 0x10000u : 1u);
-}
-
-// V = lane value type: one member per lane, or two (packed fp32: a block is 2048 members and the kernel keeps the fused
-// packed kernel's 4 waves/SIMD x 2 members, where the one-member fp32 form is held to 4 waves x 1 by its 1024-thread
-// workgroup).
-//
-// Work is handed to WAVES, not fixed per wave (round 3, profiles/r03/ab_variants.txt section 14).  A SIMD's instruction
-// arbiter favours its oldest wave: of four waves that start together and run the same 750-step loop, the first finishes
-// after ~60 % of the time the last one needs (tools/fused_timing.py).  A kernel with more workgroups than slots does not
-// care — a new workgroup takes the freed slot — but a persistent workgroup whose waves each own 1/16 of every member block
-// ends with one or two waves per SIMD crawling through their share alone (a lone wave issues at 40 % of the rate of four):
-// that tail, not the load/store phases, was the cost of this kernel's shape (+23 % on the fused kernel relaunched every K
-// steps, same instruction count).  So the workgroup's member blocks are cut into wave items (64 lanes x W members x K
-// steps) behind one LDS counter; a wave takes the next item when it finishes one, and all sixteen finish within one item
-// of each other.  Items are handed out in epochs of as many members as a 16-bit histogram lane can count; the
-// workgroup meets at the end of an epoch to flush.
-template <typename V, int P0, int P1, int P2>
-__global__ __launch_bounds__(TILE_BLOCK) void tile_kernel(
-    const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps,
-    const int t_begin, const int t_end, const int64_t n, const int64_t ld,
-    const typename Lane<V>::S* __restrict__ r, const typename Lane<V>::S* __restrict__ q,
-    typename Lane<V>::S* __restrict__ R, typename Lane<V>::S* __restrict__ S,
-    typename Lane<V>::S* __restrict__ C_traj, typename Lane<V>::S* __restrict__ T_traj, const int n_rows,
-    double* __restrict__ stats, const double hist_lo, const double hist_inv_w, const int n_bins,
-    unsigned long long* __restrict__ hist /* [n_steps][n_bins] or nullptr */) {
-    using L = Layout<P0, P1, P2>;
-    using T = typename Lane<V>::S;
-    constexpr int W = Lane<V>::W;
-    constexpr int WG_WAVES = TILE_BLOCK / 64;
-    constexpr int BLOCK_MEMBERS = TILE_BLOCK * W;
-    extern __shared__ unsigned int h_s[];                 // [nt][hw] packed 16-bit pairs (hist != nullptr)
-    // ONE static LDS object, the model and the drive rows FIRST: a ds_read reaches base + a 16-bit immediate offset, and the
-    // 66 KB of statistics tiles of a 1024-thread workgroup (packed lanes) pushed whatever the compiler laid out behind them
-    // past 64 KB — every model constant then needed its own address register and its own ds_read (no ds_read2 pairs):
-    // +7 LDS reads and +11 waits per step, ~17 VGPRs of addresses
-    struct TileShared {
-        KModel<T> km;
-        T drv[TILE_MAX_STEPS * DRIVE_STRIDE];
-        int next_item;
-        V stat[WG_WAVES][STAT_STEPS * STAT_ROW];
-    };
-    __shared__ TileShared sh;
-    T* const drv = sh.drv;
-    {
-        constexpr int NW = sizeof(KModel<T>) / sizeof(T);
-        const T* src = (const T*)__builtin_amdgcn_kernarg_segment_ptr();
-        if (threadIdx.x < NW) reinterpret_cast<T*>(&sh.km)[threadIdx.x] = src[threadIdx.x];
-    }
-    const KModel<T>& kmr = sh.km;
-    const HistRule<T> rule = make_rule(T(0), hist_lo, hist_inv_w, n_bins);
-    const int nt = t_end - t_begin;
-    const int hw = (n_bins + 1) >> 1;
-    const bool do_hist = hist != nullptr;
-    if (do_hist)
-        for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) h_s[i] = 0u;
-    for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += TILE_BLOCK) drv[i] = drive[(int64_t)t_begin * DRIVE_STRIDE + i];
-    FIVEEQ_HOOK_TILE_BEGIN
-
-    auto flush = [&]() {
-        for (int i = threadIdx.x; i < nt * hw; i += TILE_BLOCK) {
-            const unsigned int v = h_s[i];
-            if (v) {
-                const int k = i / hw, w2 = (i - k * hw) << 1;
-                unsigned long long* o = hist + (int64_t)(t_begin + k) * n_bins + w2;
-                if (v & 0xffffu) atomicAdd(o, (unsigned long long)(v & 0xffffu));
-                if (v >> 16) atomicAdd(o + 1, (unsigned long long)(v >> 16));
-                h_s[i] = 0u;
-            }
-        }
-    };
-
-    const int64_t n_blocks = (n + BLOCK_MEMBERS - 1) / BLOCK_MEMBERS;
-    const int64_t n_rec = (n + 63) >> 6;                                   // statistics records: one per 64 members
-    V* const tile = sh.stat[threadIdx.x >> 6];
-    const int lane = threadIdx.x & 63;
-    // this workgroup's member blocks are blockIdx.x, blockIdx.x + gridDim.x, ...; item = (block of the workgroup, wave slice)
-    const int my_blocks = (int)((n_blocks - blockIdx.x + gridDim.x - 1) / gridDim.x);
-    const int n_items = my_blocks * WG_WAVES;
-    const int epoch_items = do_hist ? tile_flush_blocks<V>() * WG_WAVES : n_items;      // members per epoch <= 65535
-    for (int e0 = 0; e0 < n_items; e0 += epoch_items) {
-        const int e1 = min(n_items, e0 + epoch_items);
-        if (threadIdx.x == 0) sh.next_item = e0;
-        __syncthreads();                                   // also covers the staging above (first epoch)
-        for (;;) {
-            int item = 0;
-            if (lane == 0) item = atomicAdd(&sh.next_item, 1);
-            item = __builtin_amdgcn_readfirstlane(item);
-            if (item >= e1) break;
-            const int64_t blk = blockIdx.x + (int64_t)(item / WG_WAVES) * gridDim.x;
-            const int64_t wave = blk * WG_WAVES + (item % WG_WAVES);                    // 64-lane slice of the ensemble
-            const int64_t m = (wave * 64 + lane) * W;                                    // this lane's first member
-            const bool active = m < n;
-            const bool full = m + (W - 1) < n;
-            const int64_t mm = active ? m : 0;
-            const bool wave_live = stats != nullptr && wave * W < n_rec;
-            const int n_valid = (int)min((int64_t)64 * W, n - wave * 64 * W);
-            int ks = 0;
-
-            V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
-#pragma unroll
-            for (int k = 0; k < L::SP; ++k) Rv[k] = load_lane<V>(R + k * ld + mm);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) Sv[k] = load_lane<V>(S + k * ld + mm);
-#pragma unroll
-            for (int k = 0; k < 3 * L::G; ++k) rr[k] = load_lane<V>(r + k * ld + mm);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) qq[k] = load_lane<V>(q + k * ld + mm);
-
-            for (int k = 0; k < nt; ++k) {
-                const T* d = &drv[k * DRIVE_STRIDE];
-                member_step<V, L>(kmr, d, rr, qq, Rv, Sv, Cv, Tn);
-                const int row = __builtin_amdgcn_readfirstlane((int)d[7]);
-                if (row >= 0 && row < n_rows && active) {
-                    if (C_traj != nullptr) {
-                        T* c = C_traj + (int64_t)row * L::G * ld + m;
-#pragma unroll
-                        for (int g = 0; g < L::G; ++g) store_lane(c + g * ld, Cv[g], full);
-                    }
-                    if (T_traj != nullptr) store_lane(T_traj + (int64_t)row * ld + m, Tn, full);
-                }
-                if (do_hist) {
-                    if constexpr (W == 1) {
-                        if (active) tile_hist_add(&h_s[k * hw], hist_bin(rule, Tn));
-                    } else {
-                        const unsigned int b01 = hist_bin2(rule, Tn);
-                        if (active) tile_hist_add(&h_s[k * hw], b01 & 0xffffu);
-                        if (full) tile_hist_add(&h_s[k * hw], b01 >> 16);
-                    }
-                }
-                if (wave_live) {
-                    tile[ks * STAT_ROW + lane] = Tn;
-                    if (++ks == STAT_STEPS || k + 1 == nt) {
-                        const int64_t t_first = (int64_t)(t_begin + k + 1 - ks);
-                        if constexpr (W == 1) {
-                            wave_stats_flush(tile, ks, n_valid, stats + (wave * n_steps + t_first) * 4, 4);
-                        } else {
-                            wave_stats_flush(tile, ks, n_valid, stats + (2 * wave * n_steps + t_first) * 4,
-                                             2 * wave + 1 < n_rec ? stats + ((2 * wave + 1) * n_steps + t_first) * 4 : nullptr, 4);
-                        }
-                        ks = 0;
-                    }
-                }
-            }
-            if (active) {
-#pragma unroll
-                for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
-#pragma unroll
-                for (int k = 0; k < 2; ++k) store_lane(S + k * ld + m, Sv[k], full);
-            }
-        }
-        __syncthreads();                                   // every wave is out of the epoch: counters complete, next_item free
-        if (do_hist) {
-            flush();
-            __syncthreads();
-        }
-    }
-    FIVEEQ_HOOK_TILE_END
 }
 
 // ---------------------------------------------------------------------------------
@@ -1481,15 +1286,13 @@ constexpr int HIST_MAX_BINS = 4096;
 // bin indices — because the larger LDS footprint halves / quarters the resident waves: these passes run at the box's plain
 // copy rate for their access width and are bound by memory-level parallelism, not by LDS atomics.  profiles/r04/ab_variants.txt)
 
-template <typename T, bool MOM>
+template <typename T>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n, const int64_t ld, const int64_t chunk,
                                                                  const T* __restrict__ rows, const double lo_all,
                                                                  const double inv_w_all, const int n_bins,
                                                                  unsigned long long* __restrict__ hist,
-                                                                 double* __restrict__ moments /* [rows][chunks][4] or nullptr */,
                                                                  const double* __restrict__ ranges /* [rows][2] or nullptr */) {
     __shared__ unsigned int h[HIST_MAX_BINS];
-    __shared__ double red[FIVEEQ_BLOCK / 64][4];
     for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) h[b] = 0u;
     __syncthreads();
     const int64_t row = blockIdx.y;
@@ -1500,33 +1303,17 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
     const int64_t m0 = (int64_t)blockIdx.x * chunk;
     const int64_t m1 = min(m0 + chunk, n);
     const T* x = rows + row * ld;
-    const double inf = __builtin_inf();
-    double s1 = 0.0, s2 = 0.0, mn = inf, mx = -inf;      // MOM: this pass reads every value anyway, the moments ride along
     const HistRule<T> rule = make_rule(T(0), lo, inv_w, n_bins);
     auto count = [&](const T xv) {
         const unsigned int b = hist_bin(rule, xv);                                    // a NaN has no bin and is not counted
         const bool ok = b != (unsigned int)BIN_NAN;
         wave_lds_add(&h[ok ? b : 0u], 1u, ok ? b : ~0u);
-        if constexpr (MOM) {
-            const double v = (double)xv;
-            s1 += v;
-            s2 = __builtin_fma(v, v, s2);
-            mn = fmin(mn, v);
-            mx = fmax(mx, v);
-        }
     };
     // the same value counted with a PLAIN LDS atomic: for rows that do not crowd into a few bins (see hist_bins_kernel: the
     // crowding test of wave_lds_add runs once per group of four loads, on the first of them)
     auto count_plain = [&](const T xv) {
         const unsigned int b = hist_bin(rule, xv);
         if (b != (unsigned int)BIN_NAN) atomicAdd(&h[b], 1u);
-        if constexpr (MOM) {
-            const double v = (double)xv;
-            s1 += v;
-            s2 = __builtin_fma(v, v, s2);
-            mn = fmin(mn, v);
-            mx = fmax(mx, v);
-        }
     };
     int64_t m = m0 + threadIdx.x;
     for (; m + 3 * FIVEEQ_BLOCK < m1; m += 4 * FIVEEQ_BLOCK) {      // four independent loads in flight per lane
@@ -1546,32 +1333,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
         }
     }
     for (; m < m1; m += FIVEEQ_BLOCK) count(x[m]);
-    if constexpr (MOM) {
-#pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) {
-            s1 += __shfl_xor(s1, sh);
-            s2 += __shfl_xor(s2, sh);
-            mn = fmin(mn, __shfl_xor(mn, sh));
-            mx = fmax(mx, __shfl_xor(mx, sh));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            double* r = red[threadIdx.x >> 6];
-            r[0] = s1, r[1] = s2, r[2] = mn, r[3] = mx;
-        }
-    }
     __syncthreads();
-    if (MOM && threadIdx.x == 0) {
-        double a = red[0][0], b = red[0][1], c = red[0][2], d = red[0][3];
-#pragma unroll
-        for (int w = 1; w < FIVEEQ_BLOCK / 64; ++w) {
-            a += red[w][0];
-            b += red[w][1];
-            c = fmin(c, red[w][2]);
-            d = fmax(d, red[w][3]);
-        }
-        double* o = moments + (row * gridDim.x + blockIdx.x) * 4;
-        o[0] = a, o[1] = b, o[2] = c, o[3] = d;
-    }
     unsigned long long* out = hist + row * n_bins;
     for (int b = threadIdx.x; b < n_bins; b += FIVEEQ_BLOCK) {
         const unsigned int c = h[b];
@@ -1919,8 +1681,8 @@ __global__ __launch_bounds__(PICK_BLOCK) void select_pick_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const T* const x = pool + row * n_seg * width;
     if (threadIdx.x == 0) {
-        long long total = 0;
-        for (int g = 0; g < n_seg; ++g) total += (long long)seg_n[row * n_seg + g];
+        long long total = 0;                                  // a segment holds at most `width` stored candidates, whatever was FOUND
+        for (int g = 0; g < n_seg; ++g) total += min((long long)seg_n[row * n_seg + g], (long long)width);
         long long r = ranks[row * Q + q];
         if (r < 0 || r >= total) r = -1;
         rank_s = r;
@@ -1935,7 +1697,7 @@ __global__ __launch_bounds__(PICK_BLOCK) void select_pick_kernel(
             __syncthreads();
             const U prefix = prefix_s;
             for (int g = 0; g < n_seg; ++g) {
-                const int64_t cnt = (int64_t)seg_n[row * n_seg + g];
+                const int64_t cnt = min((int64_t)seg_n[row * n_seg + g], width);
                 const T* xs = x + g * width;
                 // whole waves iterate together (wave_lds_add is a wave-level operation)
                 auto tally = [&](const T v, const bool have) {

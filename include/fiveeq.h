@@ -17,9 +17,12 @@
  *   - Plain C: pointers, sizes, one POD struct.  No torch / C++ types.
  *   - Every `dev` pointer is DEVICE memory owned by the caller (the Python host
  *     passes torch-ROCm tensor data_ptr()s).  The library allocates nothing on
- *     the device, keeps no global state except the thread-local error string,
- *     never synchronises the stream (launches are asynchronous) and is safe
- *     to call concurrently on different streams / devices.
+ *     the device, never synchronises the stream (launches are asynchronous) and is
+ *     safe to call concurrently from several threads on different streams / devices.
+ *     ALL the state it keeps: the thread-local error string (fiveeq_last_error), and ONE
+ *     process-wide word, the fp32 packing switch of fiveeq_set_f32_packing — an atomic that
+ *     every call reads once, so a call in flight while another thread flips it runs
+ *     entirely with the old or entirely with the new setting (both give the same bits).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *   - Return value: 0 = success; <0 = error (FIVEEQ_E_*), message retrievable
  *     with fiveeq_last_error() on the same thread.  Arguments are validated on
@@ -49,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   8
+#define FIVEEQ_ABI_VERSION   9
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
@@ -212,44 +215,12 @@ int fiveeq_run_small_f32(const fiveeq_model *model, int64_t n_members, int64_t l
 /* lanes per member of the widest small-ensemble form compiled for (n_gas, n_pools[]): 4, 1, or 0 = none */
 int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t *n_pools);
 
-/* TIME-TILED persistent kernel with IN-LOOP HISTOGRAMS of T: all-timestep
- * percentiles of an ensemble that stores no trajectory.  One launch per tile of k_steps steps
- * (0 = the largest tile whose LDS histogram fits, fiveeq_tile_steps_*(n_bins)); one persistent
- * 1024-thread workgroup per CU hands its member blocks to its waves in wave-sized items (a wave takes the next item when
- * it finishes one — a static share per wave leaves the slowest-served wave of every SIMD alone at the end) and accumulates
- *     T_hist[t][b] += #members with hist_lo + b*w <= T(t) < hist_lo + (b+1)*w,  w = (hist_hi - hist_lo)/n_bins
- * (outliers in the edge bins, NaNs skipped: the rule of fiveeq_hist_rows_*, bit for bit) in LDS,
- * flushing only non-zero bins to T_hist dev [n_steps][n_bins] uint64 (ACCUMULATED INTO: zero it
- * first; shards may share it).  T_hist may be NULL (no histogram; n_bins ignored).  C_traj, T_traj,
- * T_stats behave as in the other entry points; results are bit-identical to them. */
-int fiveeq_run_tiled_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
-                         const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
-                         const double *r, const double *q, double *R, double *S,
-                         double *C_traj, double *T_traj, int32_t n_rows, double *T_stats,
-                         int32_t k_steps, double hist_lo, double hist_hi, int32_t n_bins,
-                         uint64_t *T_hist, void *stream);
-int fiveeq_run_tiled_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
-                         const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
-                         const float *r, const float *q, float *R, float *S,
-                         float *C_traj, float *T_traj, int32_t n_rows, double *T_stats,
-                         int32_t k_steps, double hist_lo, double hist_hi, int32_t n_bins,
-                         uint64_t *T_hist, void *stream);
-/* largest k_steps the tiled kernel accepts for n_bins (0 = no histogram); 0 for an invalid n_bins */
-int32_t fiveeq_tile_steps_f64(int32_t n_bins);
-int32_t fiveeq_tile_steps_f32(int32_t n_bins);
-/* The fp32 entry points (step / run / run_fused / run_ksteps / run_tiled / plan_create _f32) compute TWO members per
+/* The fp32 entry points (step / run / run_fused / run_ksteps / run_*bins / plan_create _f32) compute TWO members per
  * lane with packed fp32 instructions and 8-byte row accesses whenever the rows allow it (ld even, every row pointer
  * 8-byte aligned, n_members >= 2), and one member per lane otherwise; both give the same bits.  This switch forces the
  * one-member-per-lane kernels (on = 0) or re-enables packing (on != 0, the default); returns the previous setting.
- * Process-wide; meant for measurements and tests. */
+ * Process-wide (an atomic word, see CONVENTIONS); meant for measurements and tests. */
 int fiveeq_set_f32_packing(int on);
-
-/* LDS bytes per workgroup the tile size is derived from: hipDeviceAttributeMaxSharedMemoryPerBlock of the calling
- * thread's current device (160 KiB on MI355X; the same figure is assumed when no device is visible). */
-int32_t fiveeq_tile_lds_bytes(void);
-/* diagnostic: how many times the tiled kernel's dynamic-LDS limit (hipFuncSetAttribute) has been set so far — once per
- * kernel instantiation and device, not per launch */
-int32_t fiveeq_tile_attr_calls(void);
 
 /* CONCENTRATION-DRIVEN (inverse) mode (the reference's module name
  * `concentrations` hints at it, no reference code exists).  drive[t][0..2] hold the TARGET
@@ -277,27 +248,20 @@ int fiveeq_hfc_conc_f64(int64_t n_members, int64_t ld, int32_t n_time,
 /* new — fixed-bin histograms of stored rows, for all-timestep percentiles with a tiny exchange
  * (SURVEY.md section 8e-ii): hist[row][b] += number of members with lo + b*w <= rows[row][m] < lo + (b+1)*w,
  * w = (hi - lo)/n_bins; values outside [lo, hi) are counted in the edge bins, NaNs are skipped.
- * THE BIN RULE, shared bit for bit by every entry point that bins a value (these, the in-loop histograms of
- * fiveeq_run_tiled_*, the bin indices of fiveeq_run_*bins_*, the summary's selection): with inv_w = n_bins/(hi - lo),
+ * THE BIN RULE, shared bit for bit by every entry point that bins a value (these, the bin indices of fiveeq_run_*bins_*,
+ * the summary's selection): with inv_w = n_bins/(hi - lo),
  *   _f64:  bin = trunc(clamp((x - lo) * inv_w, 0, n_bins - 1))                        evaluated in fp64
  *   _f32:  bin = trunc(clamp(fma(x, (float)inv_w, (float)(-lo*inv_w)), 0, n_bins - 1)) evaluated in fp32 (one FMA per
- *          member; a member's bin differs from the fp64 formula's only within 2^-12 of a bin edge).
+ *          member).  Monotone in x like the fp64 formula; against it a member changes bin only within
+ *          ~2^-23 * max(|lo|, |hi|) * inv_w of a bin edge (in bins): 2^-12 bin for a range that starts near zero such as
+ *          temperature anomalies, 0.01 bin for lo = 280, hi = 295, n_bins = 4096 — express rows in absolute units far from zero
+ *          as anomalies, or keep them in fp64, if that matters.
  *   rows dev [n_rows][ld] (e.g. T_traj), hist dev [n_rows][n_bins] uint64, ACCUMULATED INTO (zero it first;
  *   several shards / calls may add into the same histogram), 1 <= n_bins <= 4096, n_rows <= 65535. */
 int fiveeq_hist_rows_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double *rows,
                          double lo, double hi, int32_t n_bins, uint64_t *hist, void *stream);
 int fiveeq_hist_rows_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
                          double lo, double hi, int32_t n_bins, uint64_t *hist, void *stream);
-/* the same pass also returning the MOMENTS of every row — it reads every value anyway:
- *   moments dev [n_rows][K][4] fp64, K = fiveeq_hist_rows_chunks(n_rows, n_members): per row and member chunk
- *   (sum, sum of squares, min, max); folding over K gives the row's ensemble moments.  Lets a run that streams its
- *   T rows through this pass (engine mode "fused" with hist=) drop the in-kernel statistics. */
-int fiveeq_hist_rows_stats_f64(int32_t n_rows, int64_t n_members, int64_t ld, const double *rows,
-                               double lo, double hi, int32_t n_bins, uint64_t *hist, double *moments, void *stream);
-int fiveeq_hist_rows_stats_f32(int32_t n_rows, int64_t n_members, int64_t ld, const float *rows,
-                               double lo, double hi, int32_t n_bins, uint64_t *hist, double *moments, void *stream);
-int64_t fiveeq_hist_rows_chunks(int32_t n_rows, int64_t n_members);
-
 /* new — the END-OF-RUN SUMMARY as HIP passes (form (i): exact percentiles of T at selected output
  * times over ALL members by SELECTION, so that the ensemble does not travel; host side: fiveeqscm_amd/distributed.py).
  * All three read rows dev [n_rows][ld] once, 16 bytes per lane and load.
@@ -334,7 +298,9 @@ int fiveeq_select_bins_f32(int32_t n_rows, int64_t n_members, int64_t ld, const 
  *     marked bins below the target's bin, plus i - cdf[b-1]); one workgroup per (row, target) finds the candidate of that
  *     rank by radix selection.  pool dev [n_rows][n_seg][width]: the candidates as they arrived, seg_n dev [n_rows][n_seg]
  *     valid entries per segment (one segment: cand / cand_n of (3); on the root of a multi-rank exchange: one segment per
- *     rank).  picked dev [n_rows][n_targets] fp64; NaN where the rank is negative or not below the number of candidates. */
+ *     rank).  A segment holds at most `width` STORED candidates: seg_n entries beyond width (cand_n of (3) counts what it
+ *     found, also past cap) are taken as width.  picked dev [n_rows][n_targets] fp64; NaN where the rank is negative or not
+ *     below the number of stored candidates. */
 int fiveeq_select_pick_f64(int32_t n_rows, int32_t n_seg, int64_t width, const double *pool, const uint64_t *seg_n,
                            int32_t n_targets, const int64_t *ranks, double *picked, void *stream);
 int fiveeq_select_pick_f32(int32_t n_rows, int32_t n_seg, int64_t width, const float *pool, const uint64_t *seg_n,

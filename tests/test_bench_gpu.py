@@ -37,6 +37,16 @@ def test_default_mode_line_has_the_contract_keys():
     assert abs(r["algorithmic_bytes_per_member_step"] - 248.0) < 1e-9 and r["kernel"] == "fiveeq::step_kernel<double,4,1,1>"
     assert r["avg_launch_us"] * 1e-3 <= d["ms_per_step"] * 1.25                 # kernel time consistent with the wall figure
     assert 0.0 < r["hbm_resident_frac"] < 1.0 and r["hbm_resident"]["x_infinity_cache"] > 1.0
+    # north_star's literal shape (one launch per timestep on one stream) beside the default; 300k members run as one launch
+    # anyway, so the two figures are one measurement here
+    assert r["single_launch"]["frac"] == r["single_launch_frac"] and 0.0 < r["single_launch_frac"] < 1.2
+    assert (r["concurrent_launches"] == 1) == (r["single_launch_avg_us"] == r["avg_launch_us"])
+    # the scalars a reader needs come FIRST in the object (the driver's parser keeps the head of a nested object)
+    assert list(r)[:8] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_resident_frac", "single_launch_frac"]
+    assert d["config"]["mode_resolved"] == "per_step" and len(d["config"]["devices"]) == 1
+    dev0 = d["config"]["devices"][0]
+    assert dev0["rank"] == 0 and dev0["device_index"] == 0 and dev0["name"] and len(dev0["pci_bus_id"].split(":")) == 3
+    assert len(d["timing"]["per_rank_ms_per_step"]) == 1 and abs(d["timing"]["per_rank_ms_per_step"][0] - d["ms_per_step"]) < 1e-9
     assert "workload" in d["config"] and "model" not in d["config"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
@@ -57,10 +67,15 @@ def test_fused_family_lines_price_their_own_kernel():
     r = d["roofline"]
     assert r["bound"] == "fp64-valu" and r["kernel"].startswith("fiveeq::fused_kernel<double") and "cpu_baseline" not in d
     assert r["algorithmic_bytes_per_member_step"] < 40.0 and r["steps_per_launch"] == 128      # 200k members: relaunched (fused_span)
+    # BASELINE configs[1]: --mode auto is the small-ensemble kernel, one member per quad of lanes
     d2 = _bench("--workload", "config2", "--mode", "auto", "--no-cpu-baseline", "--kernel-batches", "2")
-    assert d2["config"]["steps_per_launch"] > 1 and d2["roofline"]["kernel"].startswith("fiveeq::fused_kernel<double,4,0,0")
+    assert d2["config"]["mode"] == "auto" and d2["config"]["mode_resolved"] == "small" and d2["config"]["steps_per_launch"] == 750
+    r2 = d2["roofline"]
+    assert r2["kernel"] == "fiveeq::small_kernel<double,4,4>" and r2["lanes_per_member"] == 4 and r2["waves"] == 625
     d3 = _bench("--workload", "config2", "--no-cpu-baseline", "--kernel-batches", "1", "--no-hbm-resident")
-    assert d2["value"] > 1.5 * d3["value"]                      # K steps per launch beats the launch-bound per-step form
+    assert d2["value"] > 3.0 * d3["value"]                      # ... against the launch-bound per-step form
+    d4 = _bench("--workload", "config2", "--mode", "ksteps", "--no-cpu-baseline", "--kernel-batches", "2")
+    assert d4["roofline"]["kernel"].startswith("fiveeq::fused_kernel<double,4,0,0") and d2["value"] > 1.3 * d4["value"]
 
 
 # ---- the N > 1 path: exactly what the driver launches on a multi-GPU node, rehearsed on the one GPU of the test box ----
@@ -121,6 +136,17 @@ def test_multi_rank_launch_prints_one_line_and_the_world_size_invariant_summary(
     lo_ms, med_ms, hi_ms = d["timing"]["block_ms_min_median_max"]
     assert lo_ms <= med_ms <= hi_ms and abs(med_ms - d["ms_per_step"] * 20) < 1e-9 * med_ms
     assert d["summary"]["bytes_to_root"] > 0 and d["summary"]["years"] == [24]
+    # the line proves what ran: n distinct ranks, their devices, their own timings, and the exchange group as it reports itself
+    devs = d["config"]["devices"]
+    assert [x["rank"] for x in devs] == list(range(n)) and len({x["pid"] for x in devs}) == n
+    assert all(x["name"] and x["device_index"] == x["local_rank"] % x["visible_devices"] for x in devs)
+    t = d["timing"]
+    assert len(t["per_rank_ms_per_step"]) == n == len(t["per_rank_host_enqueue_us"]) and min(t["per_rank_ms_per_step"]) > 0
+    assert max(t["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.5 and max(t["per_rank_host_enqueue_us"]) <= t["host_enqueue_us_per_step"] * 1.0001
+    sm = d["summary"]
+    assert sm["rccl_world_size"] == n and sm["backend_seen"] == "gloo"             # (the rehearsal's data group is gloo)
+    assert len(sm["bytes_to_root_per_rank"]) == n and sm["bytes_to_root_per_rank"][0] == 0
+    assert sum(sm["bytes_to_root_per_rank"]) == sm["bytes_to_root"] and all(b > 0 for b in sm["bytes_to_root_per_rank"][1:])
     # ONE design for every world size (the shard-computable Latin hypercube) and members never interact: the summary
     # of n ranks x 200k members is the summary of one rank with n x 200k members.  End to end through the launcher,
     # the sharding, the kernels and the exchange.
@@ -241,7 +267,8 @@ def test_one_rank_job_runs_every_collective_over_rccl():
     d = _one_line(out)
     plain = _bench(*_SMALL)
     assert d["n_gpus"] == 1 and d["config"]["collective_backend"] == "rccl" and d["summary"]["allreduce_bytes"] > 0
-    assert plain["summary"]["allreduce_bytes"] == 0
+    assert d["summary"]["rccl_world_size"] == 1 and d["summary"]["backend_seen"] == "nccl"        # as the RCCL group reports itself
+    assert plain["summary"]["allreduce_bytes"] == 0 and plain["summary"]["rccl_world_size"] is None
     assert d["summary"]["T_mean"] == pytest.approx(plain["summary"]["T_mean"], rel=1e-12)
     for a_, b_ in zip(d["summary"]["T_p05_p50_p95"], plain["summary"]["T_p05_p50_p95"]):
         assert a_ == pytest.approx(b_, rel=1e-12)

@@ -186,41 +186,105 @@ def test_latin_hypercube_is_stratified_and_seeded():
 
 
 def test_new_entry_points_validate_on_the_host():
-    """ABI v4 additions: K-steps, tiled + in-loop histograms, histogram pass with moments.  Bad arguments return on the
-    host (fake pointers are never dereferenced, nothing is launched)."""
+    """K-steps and the small-ensemble form.  Bad arguments return on the host (fake pointers are never dereferenced,
+    nothing is launched)."""
     lib = _capi.load()
     m = prm.make_model(prm.default_params("multigas"))
     p = ctypes.c_void_p(0x1000)
     common = (ctypes.byref(m), 8, 8, p, 4, 0, 4, p, p, p, p, None, None, 0, None)
     assert lib.fiveeq_run_ksteps_f64(*common, 0, None) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
     assert lib.fiveeq_run_ksteps_f32(*common, -3, None) == _capi.E_INVALID
-    tiled = lambda k, lo, hi, nb, hist: lib.fiveeq_run_tiled_f64(*common, k, lo, hi, nb, hist, None)   # noqa: E731
-    assert tiled(0, 0.0, 1.0, 0, p) == _capi.E_INVALID and b"n_bins" in lib.fiveeq_last_error()
-    assert tiled(0, 0.0, 1.0, 5000, p) == _capi.E_INVALID
-    assert tiled(0, 1.0, 1.0, 64, p) == _capi.E_INVALID and b"lo < hi" in lib.fiveeq_last_error()
-    assert tiled(0, 0.0, float("inf"), 64, p) == _capi.E_INVALID
-    assert tiled(65, 0.0, 1.0, 0, None) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
-    assert tiled(lib.fiveeq_tile_steps_f64(4096) + 1, 0.0, 1.0, 4096, p) == _capi.E_INVALID
-    # the LDS budget: K x 8 KiB of histogram beside the kernel's statistics tiles and drive table
-    assert lib.fiveeq_tile_steps_f64(4096) == 11 and lib.fiveeq_tile_steps_f32(4096) == 11
-    assert lib.fiveeq_tile_steps_f64(0) == 64 and lib.fiveeq_tile_steps_f32(1024) == 46 and lib.fiveeq_tile_steps_f64(1024) == 45
-    assert lib.fiveeq_tile_steps_f64(-1) == 0 and lib.fiveeq_tile_steps_f32(4097) == 0
-    stats = lambda rows, moments: lib.fiveeq_hist_rows_stats_f32(2, 100, 100, rows, 0.0, 1.0, 16, p, moments, None)   # noqa: E731
-    assert stats(p, None) == _capi.E_INVALID and b"moments" in lib.fiveeq_last_error()
-    assert stats(None, p) == _capi.E_INVALID
-    assert lib.fiveeq_hist_rows_chunks(0, 100) == 0 and lib.fiveeq_hist_rows_chunks(1, 100) == 1
-    assert lib.fiveeq_hist_rows_chunks(1, 12_500_000) == 12_500_000 // 16384 + 1          # >= 16384 members per workgroup
-    assert lib.fiveeq_hist_rows_chunks(750, 12_500_000) == 3                              # ~2048 workgroups over all rows
+    # the small-ensemble kernel: single-gas layouts only; 4 lanes per member for a lone 4-pool gas, 1 for the others
+    lanes = lambda *pl: lib.fiveeq_small_lanes(len(pl), (ctypes.c_int32 * len(pl))(*pl))   # noqa: E731
+    assert [lanes(4), lanes(1), lanes(2), lanes(3), lanes(4, 1, 1), lanes(1, 1), lanes(5)] == [4, 1, 1, 1, 0, 0, 0]
+    small = lambda model, n_lanes, t0=0, t1=4: lib.fiveeq_run_small_f64(ctypes.byref(model), 8, 8, p, 4, t0, t1, p, p, p, p, None,   # noqa: E731
+                                                                       None, 0, n_lanes, None)
+    assert small(m, 0) == _capi.E_UNSUPPORTED and b"small-ensemble" in lib.fiveeq_last_error()
+    co2 = prm.make_model(prm.default_params("co2"))
+    assert small(co2, 2) == _capi.E_INVALID and b"lanes_per_member" in lib.fiveeq_last_error()
+    assert small(co2, -1) == _capi.E_INVALID
+    assert small(co2, 4, 3, 2) == _capi.E_INVALID                      # the shared checks: step range
+    for n_lanes in (0, 1, 4):
+        assert small(co2, n_lanes, 2, 2) == _capi.OK                   # empty span: nothing to launch
+    assert lib.fiveeq_run_small_f32(ctypes.byref(co2), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, 0, None) == _capi.OK
+    one_pool = dict(prm.default_params("co2"))
+    bad = lib.fiveeq_run_small_f64(ctypes.byref(co2), 8, 8, None, 4, 0, 4, p, p, p, p, None, None, 0, 0, None)
+    assert bad == _capi.E_INVALID and b"NULL" in lib.fiveeq_last_error() and one_pool
+
+
+def test_an_experiment_build_is_refused_unless_asked_for(monkeypatch):
+    """A variant compiled with experiment knobs carries the product's source hash; fiveeq_build_flags() tells it apart and
+    load() refuses it (advisor, round 4)."""
+    lib = _capi.load()
+
+    class Variant:
+        def __getattr__(self, name):
+            if name == "fiveeq_build_flags":
+                return lambda: b" FIVEEQ_SMALL_BLOCK=64"
+            return getattr(lib, name)
+
+    monkeypatch.setattr(ctypes, "CDLL", lambda path: Variant())
+    monkeypatch.delenv("FIVEEQ_ALLOW_STALE_LIB", raising=False)
+    with pytest.raises(ImportError, match="experiment build"):
+        _capi.load(_capi.LIB_PATH)
+    monkeypatch.setenv("FIVEEQ_ALLOW_STALE_LIB", "1")
+    assert _capi.build_flags(_capi.load(_capi.LIB_PATH)) == "FIVEEQ_SMALL_BLOCK=64"
+
+
+def test_concurrent_calls_and_the_packing_switch():
+    """include/fiveeq.h, CONVENTIONS: safe to call from several threads; the only process-wide state is the fp32 packing
+    switch, an atomic.  Eight threads hammer the validation paths of fiveeq_step_f32 / fiveeq_run_small_f32 (every call fails
+    or is an empty span: nothing is launched) while a ninth flips the switch; every thread must see ITS OWN error text
+    (thread-local) and the switch must end where the last writer left it.  tools/sanitize_host.sh runs this under the
+    ASan + UBSan host build."""
+    import threading
+    lib = _capi.load()
+    m = prm.make_model(prm.default_params("multigas"))
+    p = ctypes.c_void_p(0x1000)
+    errors, stop = [], threading.Event()
+
+    def worker(k):
+        try:
+            for i in range(3000):
+                if k % 2:
+                    rc = lib.fiveeq_step_f32(ctypes.byref(m), 8, 8, p, 4, 4 + k, p, p, p, p, None, None, 0, None, None)
+                    want = f"t={4 + k} outside".encode()
+                else:
+                    rc = lib.fiveeq_run_f32(ctypes.byref(m), 8, 4 - (k % 3), p, 4, 0, 4, p, p, p, p, None, None, 0, None, None)
+                    want = f"ld={4 - (k % 3)} <".encode()
+                if rc != _capi.E_INVALID or want not in lib.fiveeq_last_error():
+                    errors.append((k, i, rc, lib.fiveeq_last_error()))
+                    return
+                if lib.fiveeq_run_f32(ctypes.byref(m), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, None, None) != _capi.OK:
+                    errors.append((k, i, "empty span"))
+                    return
+        except Exception as exc:  # noqa: BLE001
+            errors.append((k, repr(exc)))
+
+    def flipper():
+        v = 0
+        while not stop.is_set():
+            lib.fiveeq_set_f32_packing(v)
+            v ^= 1
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    flip = threading.Thread(target=flipper)
+    flip.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    stop.set()
+    flip.join()
+    assert not errors, errors[:3]
+    assert lib.fiveeq_set_f32_packing(1) in (0, 1) and lib.fiveeq_set_f32_packing(1) == 1
 
 
 def test_abi_v5_host_side_guards():
-    """ABI v5: the tile size comes from the device's LDS attribute (the gfx950 figure without a device), the tiled
-    kernel's dynamic-LDS limit is set once per instantiation (never here: nothing is launched), K-step spans are clamped
-    to the step range before any loop arithmetic, and Latin-hypercube designs stop at 2^28 members, where stratum +
-    jitter is still an exact fp64 sum."""
+    """K-step spans are clamped to the step range before any loop arithmetic, and Latin-hypercube designs stop at 2^28
+    members, where stratum + jitter is still an exact fp64 sum."""
     import numpy as np
     lib = _capi.load()
-    assert lib.fiveeq_tile_lds_bytes() == 160 * 1024 and lib.fiveeq_tile_attr_calls() == 0
     m = prm.make_model(prm.default_params("multigas"))
     p = ctypes.c_void_p(0x1000)
     empty = (ctypes.byref(m), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, None)       # t_begin == t_end: nothing to launch

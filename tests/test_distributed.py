@@ -1,5 +1,7 @@
-"""The N>1 path on CPU: world_size-2 gloo processes exercise sharding + the end-of-run summary
-exchange (the same code that runs over RCCL on the GPUs)."""
+"""The N>1 path on CPU: world_size-2 (and 3, 8) gloo processes exercise sharding + the end-of-run summary exchange — the
+product's host logic (fiveeqscm_amd.distributed: which bins are marked, the rank bookkeeping, the exchanges) with the four HIP
+passes replaced by their NumPy restatement (oracle/summary_passes.py), i.e. the same code that runs over RCCL on the GPUs; and,
+as a second route to the same numbers, the torch-ops restatement of the whole summary (oracle/summary_host.py)."""
 import os
 import socket
 
@@ -8,8 +10,47 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from fiveeqscm_amd.distributed import (gather_summary, histogram_percentiles, local_moments, merge_moments,
-                                       moments_from_sums, percentiles_sorted, reduce_stats, shard_bounds)
+from fiveeqscm_amd.distributed import (gather_summary, histogram_percentiles, merge_moments, moments_from_sums,
+                                       percentiles_sorted, reduce_stats, shard_bounds)
+from oracle import summary_host
+from oracle.summary_host import local_moments
+
+
+def _use_oracle_passes():
+    """The product's summary takes device rows through the HIP passes; here (no GPU) the passes are the NumPy restatement
+    behind the same signatures, and host rows are let in."""
+    import ctypes
+
+    from fiveeqscm_amd import distributed
+    from oracle.summary_passes import SummaryPasses
+
+    class _Check:
+        @staticmethod
+        def check(lib, rc):
+            assert rc == 0
+
+    passes = SummaryPasses()
+    distributed._lib_and_stream = lambda rows: (passes, _Check, ctypes, None)
+    distributed._passes_apply = lambda rows: rows.dtype in (torch.float32, torch.float64)
+
+
+@pytest.fixture
+def numpy_passes():
+    from fiveeqscm_amd import distributed
+    saved = distributed._lib_and_stream, distributed._passes_apply
+    _use_oracle_passes()
+    yield
+    distributed._lib_and_stream, distributed._passes_apply = saved
+
+
+def test_host_rows_are_refused_by_the_product():
+    """No CPU fallback: rows on the host raise (the torch-ops restatement lives under oracle/, for tests)."""
+    x = torch.arange(12, dtype=torch.float64).reshape(2, 6)
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        gather_summary(x, percentiles=(50.0,))
+    from fiveeqscm_amd.distributed import exact_percentiles
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        exact_percentiles(x, (50.0,), x.min(1).values, x.max(1).values, 6)
 
 
 def test_shard_bounds_cover_and_balance():
@@ -66,15 +107,17 @@ def test_histogram_percentiles_within_one_bin_width():
     assert np.abs(got.numpy() - want)[:, 1:4].max() < 4e-4            # in-bin interpolation: better where bins are full
 
 
-def test_single_process_summary_needs_no_process_group():
+def test_single_process_summary_needs_no_process_group(numpy_passes):
     x = torch.arange(12, dtype=torch.float64).reshape(2, 6)
-    s = gather_summary(x, percentiles=(50.0,))
-    assert s["percentiles"][:, 0].tolist() == [2.5, 8.5] and s["count"].tolist() == [6.0, 6.0]
+    for fn in (gather_summary, summary_host.gather_summary):
+        s = fn(x, percentiles=(50.0,))
+        assert s["percentiles"][:, 0].tolist() == [2.5, 8.5] and s["count"].tolist() == [6.0, 6.0]
 
 
 def _worker(rank, world, port, n_total, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
+    _use_oracle_passes()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rng = np.random.default_rng(42)
@@ -83,6 +126,7 @@ def _worker(rank, world, port, n_total, q):
         s = gather_summary(torch.from_numpy(full[:, lo:hi].copy()), percentiles=(5.0, 50.0, 95.0))
         close = (49.9, 50.0, 50.0, 50.1, 0.0, 100.0)              # overlapping candidate intervals, a duplicate, the extremes
         s2 = gather_summary(torch.from_numpy(full[:, lo:hi].copy()), percentiles=close)
+        h2 = summary_host.gather_summary(torch.from_numpy(full[:, lo:hi].copy()), percentiles=close)   # the second route
         x = torch.from_numpy(full[:, lo:hi].copy())
         sums = torch.stack([torch.full((3,), float(hi - lo), dtype=torch.float64), x.sum(1), (x * x).sum(1),
                             x.min(1).values, x.max(1).values], dim=1)
@@ -102,10 +146,12 @@ def _worker(rank, world, port, n_total, q):
                   and np.allclose(s["var"].numpy(), full.var(1), rtol=1e-12)
                   and s["count"].tolist() == [float(n_total)] * 3
                   and np.array_equal(s["min"].numpy(), full.min(1)) and np.array_equal(s["max"].numpy(), full.max(1)))
-            ok = ok and np.allclose(s2["percentiles"].numpy(), np.percentile(full, close, axis=1).T, rtol=1e-13)
+            ok = ok and np.array_equal(s2["percentiles"].numpy(), np.percentile(full, close, axis=1).T)      # bit for bit
+            ok = ok and np.allclose(h2["percentiles"].numpy(), s2["percentiles"].numpy(), rtol=1e-13)
             q.put(bool(ok and stats_ok))
         else:
-            q.put(bool(stats_ok and s["percentiles"] is None and s2["percentiles"] is None and abs(float(s["mean"][0]) - full[0].mean()) < 1e-12))
+            q.put(bool(stats_ok and s["percentiles"] is None and s2["percentiles"] is None and h2["percentiles"] is None
+                       and abs(float(s["mean"][0]) - full[0].mean()) < 1e-12))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -129,9 +175,9 @@ def test_gloo_world2_summary_exchange(n_total):
 
 
 def test_selection_percentiles_edge_cases():
-    """exact_percentiles (the multi-rank path, called directly) and gather_summary (one rank: sort): ties, constant
-    rows, tiny rows, fp32 rows kept in fp32 on the wire."""
-    from fiveeqscm_amd.distributed import exact_percentiles
+    """The torch-ops restatement (oracle/summary_host.py): exact_percentiles (its multi-rank path, called directly) and
+    gather_summary (one rank: sort): ties, constant rows, tiny rows, fp32 rows kept in fp32 on the wire."""
+    from oracle.summary_host import exact_percentiles, gather_summary
     rng = np.random.default_rng(5)
     for n in (1, 2, 5, 1000, 200_001):
         x = np.stack([rng.normal(size=n), rng.uniform(size=n) ** 3, np.full(n, 2.5), np.round(rng.normal(size=n), 1)])
@@ -148,11 +194,11 @@ def test_selection_percentiles_edge_cases():
 
 
 def test_selection_percentiles_many_rows_in_blocks(monkeypatch):
-    """All-timestep shape of exact_percentiles: many rows, processed in blocks of rows (the block size forced small so
-    that a block boundary falls inside the loop), percentiles so close that their candidate intervals overlap (a row's
-    candidates travel once), a constant row in the middle."""
-    from fiveeqscm_amd import distributed
-    from fiveeqscm_amd.distributed import exact_percentiles
+    """All-timestep shape of the torch-ops exact_percentiles: many rows, processed in blocks of rows (the block size forced
+    small so that a block boundary falls inside the loop), percentiles so close that their candidate intervals overlap (a
+    row's candidates travel once), a constant row in the middle."""
+    from oracle import summary_host as distributed
+    from oracle.summary_host import exact_percentiles
     rng = np.random.default_rng(11)
     K, n = 37, 30_011
     x = rng.normal(size=(K, n)) * rng.uniform(0.1, 5.0, size=(K, 1)) + rng.normal(size=(K, 1))
@@ -182,6 +228,7 @@ def _worker8(rank, world, port, q):
     import torch.distributed as dist
     from fiveeqscm_amd import emissions, params
     from oracle import c_oracle
+    _use_oracle_passes()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         base = params.default_params("multigas")
@@ -224,7 +271,7 @@ def test_gloo_world8_config4_rehearsal_against_the_oracle():
     assert all(results)
 
 
-def test_forced_collectives_in_a_one_rank_group():
+def test_forced_collectives_in_a_one_rank_group(numpy_passes):
     """force_collectives: in a process group of ONE rank every collective of the summary exchange executes on the
     backend instead of being skipped — here over gloo; tests/test_distributed_gpu.py runs the same over RCCL on one
     GPU.  Results must equal the no-process-group answers."""
@@ -263,8 +310,9 @@ def test_forced_collectives_in_a_one_rank_group():
             setattr(dist, name, fn)
         D.force_collectives(prev)
         dist.destroy_process_group()
-    # moments all_gather; histogram + below-counts all_reduce; sizes all_gather; candidates gather; 3 + 1 all_reduces
-    assert calls.count("all_gather") == 2 and calls.count("gather") == 1 and calls.count("all_reduce") == 2 + 3 + 1
+    # summary: moments all_gather, histogram all_reduce, candidate counts all_gather, candidates gather; then reduce_stats'
+    # 3 all_reduces and histogram_percentiles' one
+    assert calls.count("all_gather") == 2 and calls.count("gather") == 1 and calls.count("all_reduce") == 1 + 3 + 1
     np.testing.assert_allclose(got["percentiles"].numpy(), np.percentile(rows.numpy(), (5.0, 50.0, 95.0), axis=1).T,
                                rtol=1e-13)
     np.testing.assert_allclose(got["percentiles"].numpy(), want["percentiles"].numpy(), rtol=1e-13)
@@ -279,22 +327,6 @@ def test_forced_collectives_in_a_one_rank_group():
 # bookkeeping in between) run on CPU tensors against the NumPy restatement of the four passes (oracle/summary_passes.py): the
 # container without a GPU still exercises which bins are marked, the rank arithmetic, the packed upload, and the multi-rank
 # exchange with one candidate segment per rank on the root -------------------------------------------------------------------
-def _use_oracle_passes():
-    import ctypes
-
-    from fiveeqscm_amd import distributed
-    from oracle.summary_passes import SummaryPasses
-
-    class _Check:
-        @staticmethod
-        def check(lib, rc):
-            assert rc == 0
-
-    passes = SummaryPasses()
-    distributed._lib_and_stream = lambda rows: (passes, _Check, ctypes, None)
-    distributed._passes_apply = lambda rows: rows.dtype in (torch.float32, torch.float64)
-
-
 def _worker_passes(rank, world, port, n_total, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist

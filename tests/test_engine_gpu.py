@@ -265,8 +265,7 @@ def test_fused_and_graph_paths_are_bit_identical_to_per_step(gpu, kind, G, N, n_
     E = emi.rcp_like_emissions(n_steps, G)
     ref = _engine(p, N, E)
     ref.run(mode="per_step")
-    for mode, k in (("fused", None), ("graph", None), ("ksteps", 1), ("ksteps", 7), ("ksteps", 16), ("tiled", 0),
-                    ("tiled", 5), ("auto", None)):
+    for mode, k in (("fused", None), ("graph", None), ("ksteps", 1), ("ksteps", 7), ("ksteps", 16), ("auto", None)):
         eng = _engine(p, N, E)
         eng.run(mode=mode, k_steps=k)
         torch.cuda.synchronize()
@@ -282,13 +281,122 @@ def test_fp32_modes_are_bit_identical_too(gpu):
     E = emi.rcp_like_emissions(750, 3)[250:250 + n_steps]
     ref = _engine(p, N, E, dtype=torch.float32)
     ref.run(mode="per_step")
-    for mode, k in (("fused", None), ("graph", None), ("ksteps", 9), ("tiled", 0), ("tiled", 7)):
+    for mode, k in (("fused", None), ("graph", None), ("ksteps", 9), ("auto", None)):
         eng = _engine(p, N, E, dtype=torch.float32)
         eng.run(mode=mode, k_steps=k)
         torch.cuda.synchronize()
         for name in ("C", "T", "R", "S"):
             assert torch.equal(getattr(eng, name), getattr(ref, name)), (mode, k, name)
         eng.close()
+
+
+def test_small_ensemble_kernel_config2_full_size_matches_the_oracle_and_the_per_step_path(gpu):
+    """BASELINE configs[1] at full size: 10,000 CO2-only fp64 members x 750 steps through fiveeq_run_small_* — one member per
+    QUAD of lanes (pool per lane; the sums over pools folded with DPP moves in the per-step order) and the same kernel
+    unspread — against the C oracle at <= 1e-10 relative on C and T, and torch.equal to the per-step path (C, T, R, S)."""
+    N, n_steps = 10_000, 750
+    p = prm.sample_ensemble(prm.default_params("co2"), N)
+    E = emi.rcp_like_emissions(n_steps, 1)
+    want = c_oracle.run(E, p, N, n_threads=8)
+    ref = _engine(p, N, E)
+    ref.run(mode="per_step")
+    for lanes in (4, 1, "auto"):
+        eng = _engine(p, N, E, small_lanes=lanes)
+        assert eng.small_form() == (4 if lanes == "auto" else lanes)
+        eng.run(mode="small")
+        torch.cuda.synchronize()
+        _close(eng.C, want["C"], what=f"C lanes={lanes}")
+        _close(eng.T, want["T"], what=f"T lanes={lanes}")
+        for name in ("C", "T", "R", "S"):
+            assert torch.equal(getattr(eng, name), getattr(ref, name)), (lanes, name)
+        eng.close()
+    auto = _engine(p, N, E)
+    auto.run(mode="auto")
+    torch.cuda.synchronize()
+    assert auto.last_mode == "small" and torch.equal(auto.T, ref.T) and torch.equal(auto.R, ref.R)
+    auto.close(), ref.close()
+
+
+def test_small_ensemble_kernel_ragged_sizes_layouts_and_resume(gpu):
+    """The small-ensemble kernel at ragged sizes (the last quad / wave / workgroup partly idle), both precisions, every
+    single-gas layout (1-3 pools: one lane per member only), selected output rows, no stored concentrations, a run resumed
+    mid-way and a member sub-range of a larger allocation: bit-identical to the per-step path every time."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(55)
+    n_steps = 140                                                    # > one 125-step chunk of the drive table
+    E = emi.rcp_like_emissions(750, 1)[200:200 + n_steps]
+    for N in (1, 3, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 16_385):
+        for td in (torch.float64, torch.float32):
+            p = prm.sample_ensemble(prm.default_params("co2"), N, seed=N)
+            kw = dict(dtype=td, output_steps=sorted(set(int(v) for v in rng.integers(0, n_steps, size=5))),
+                      store_concentrations=bool(rng.integers(0, 2)))
+            ref = _engine(p, N, E, **kw)
+            ref.run(mode="per_step")
+            for lanes in (1, 4):
+                eng = _engine(p, N, E, small_lanes=lanes, **kw)
+                cut = int(rng.integers(1, n_steps))
+                eng.run(0, cut, mode="small")
+                eng.run(cut, n_steps, mode="small")
+                torch.cuda.synchronize()
+                for name in ("T", "R", "S") + (("C",) if kw["store_concentrations"] else ()):
+                    assert torch.equal(getattr(eng, name), getattr(ref, name)), (N, td, lanes, cut, name)
+                eng.close()
+            ref.close()
+    # 1-3 pools: lanes_per_member = 1 is the only form (4 is refused)
+    for pools in (1, 2, 3):
+        base = prm.default_params("co2")
+        a0, tau0 = np.asarray(base["a"], dtype=np.float64)[0], np.asarray(base["tau"], dtype=np.float64)[0]
+        base = dict(base, a=[list(a0[:pools] / a0[:pools].sum()) + [0.0] * (4 - pools)], tau=[list(tau0[:pools]) + [1.0] * (4 - pools)])
+        p = prm.sample_ensemble(base, 777, seed=pools)
+        ref = _engine(p, 777, E)
+        ref.run(mode="per_step")
+        eng = _engine(p, 777, E)
+        assert eng.small_widest == 1 and eng.small_form() == 1
+        eng.run(mode="small")
+        torch.cuda.synchronize()
+        assert torch.equal(eng.T, ref.T) and torch.equal(eng.C, ref.C) and torch.equal(eng.R, ref.R)
+        with pytest.raises(ValueError, match="small"):
+            _engine(p, 777, E, small_lanes=4).run(mode="small")
+        eng.close(), ref.close()
+    # a member sub-range of a larger allocation through the raw C ABI: members outside untouched
+    N = 1000
+    p = prm.sample_ensemble(prm.default_params("co2"), N, seed=9)
+    ref = _engine(p, N, E)
+    ref.run(mode="per_step")
+    for m0, n in ((0, 999), (128, 129), (1, 998), (333, 64), (999, 1)):
+        for lanes in (1, 4):
+            eng = _engine(p, N, E)
+            rc = lib.fiveeq_run_small_f64(*eng._run_args(0, n_steps, m0, n)[:-1], lanes, eng._stream())
+            assert rc == 0, lib.fiveeq_last_error()
+            torch.cuda.synchronize()
+            assert torch.equal(eng.T[:, m0:m0 + n], ref.T[:, m0:m0 + n]) and torch.equal(eng.R[:, m0:m0 + n], ref.R[:, m0:m0 + n])
+            assert int((eng.T[:, :m0] != 0).sum()) == 0 and int((eng.T[:, m0 + n:] != 0).sum()) == 0, (m0, n, lanes)
+            eng.close()
+    ref.close()
+
+
+def test_auto_takes_the_small_ensemble_kernel_where_the_measured_table_says(gpu):
+    """profiles/r05/small_ensemble_ab.txt: the quad form while its waves get a SIMD each (64 members per CU), the one-lane form
+    up to 100k members, then the K-step / per-step family; never with statistics, histograms, several gases or the inverse
+    form."""
+    E = emi.rcp_like_emissions(30, 1)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for N, mode, lanes in ((10_000, "small", 4), (64 * cus, "small", 4), (64 * cus + 1, "small", 1), (100_000, "small", 1),
+                           (100_001, "ksteps", 1), (4_000_000, "per_step", 1)):
+        p = prm.sample_ensemble_shard(prm.default_params("co2"), N, device="cuda:0")
+        eng = _engine(p, N, E, store_trajectory=N < 1_000_000)
+        assert eng.resolve_mode("auto")[0] == mode and (mode != "small" or eng.small_form() == lanes), (N, mode, lanes)
+        eng.close()
+    p = prm.sample_ensemble(prm.default_params("co2"), 5000)
+    assert _engine(p, 5000, E, collect_stats=True).resolve_mode("auto")[0] == "ksteps"
+    assert _engine(p, 5000, E, hist=(-1.0, 5.0, 64)).resolve_mode("auto")[0] == "fused"
+    assert _engine(p, 5000, E).resolve_mode("auto", 7) == ("ksteps", 7)               # an explicit K is taken as given
+    pm = prm.sample_ensemble(prm.default_params("multigas"), 5000)
+    em = _engine(pm, 5000, emi.rcp_like_emissions(30, 3))
+    assert em.small_widest == 0 and em.resolve_mode("auto")[0] == "ksteps"
+    with pytest.raises(ValueError, match="single-gas"):
+        em.run(mode="small")
 
 
 def test_packed_fp32_lanes_equal_scalar_lanes_bit_for_bit(gpu):
@@ -326,26 +434,28 @@ def test_packed_fp32_lanes_equal_scalar_lanes_bit_for_bit(gpu):
                     assert torch.allclose(ra[:, :, :2], rb[:, :, :2], rtol=1e-13, atol=1e-11), (kind, N, mode)
                     a.close()
                     b.close()
-        # the time-tiled kernel: packed blocks are 2048 members; its in-loop histogram must count every member once
+        # the bin-index ring: packed lanes write two 2-byte indices as one word; every member must be counted once
         E = emi.rcp_like_emissions(750, 3)[255:255 + n_steps]
         for N in (2, 130, 2050, 4098, 20_000):
             p = prm.sample_ensemble(prm.default_params("multigas"), N, seed=N)
-            runs = []
-            for packing in (1, 0):
-                lib.fiveeq_set_f32_packing(packing)
-                eng = _engine(p, N, E, dtype=torch.float32, collect_stats=True, hist=(-1.0, 5.0, 1000))
-                eng.run(mode="tiled", k_steps=int(rng.integers(0, 12)))
-                torch.cuda.synchronize()
-                runs.append(eng)
-            a, b = runs
-            for name in ("C", "T", "R", "S", "T_hist"):
-                assert torch.equal(getattr(a, name), getattr(b, name)), ("tiled", N, name)
-            assert a.T_hist.sum(1).tolist() == [N] * n_steps
-            assert torch.equal(a.T_hist, a.T_histogram(-1.0, 5.0, 1000))
-            sa, sb = a.stats_sums(), b.stats_sums()
-            assert torch.equal(sa[:, [0, 3, 4]], sb[:, [0, 3, 4]]) and torch.allclose(sa[:, 1:3], sb[:, 1:3], rtol=1e-13, atol=1e-11)
-            a.close()
-            b.close()
+            for mode in ("fused", "per_step"):
+                runs = []
+                for packing in (1, 0):
+                    lib.fiveeq_set_f32_packing(packing)
+                    eng = _engine(p, N, E, dtype=torch.float32, collect_stats=True, hist=(-1.0, 5.0, 1000),
+                                  hist_ring_steps=int(rng.integers(1, 12)))
+                    eng.run(mode=mode)
+                    torch.cuda.synchronize()
+                    runs.append(eng)
+                a, b = runs
+                for name in ("C", "T", "R", "S", "T_hist"):
+                    assert torch.equal(getattr(a, name), getattr(b, name)), (mode, N, name)
+                assert a.T_hist.sum(1).tolist() == [N] * n_steps
+                assert torch.equal(a.T_hist, a.T_histogram(-1.0, 5.0, 1000))
+                sa, sb = a.stats_sums(), b.stats_sums()
+                assert torch.equal(sa[:, [0, 3, 4]], sb[:, [0, 3, 4]]) and torch.allclose(sa[:, 1:3], sb[:, 1:3], rtol=1e-13, atol=1e-11)
+                a.close()
+                b.close()
         # an odd member count inside an even-strided allocation (the last packed lane stores one member only), and a
         # sub-range that starts at an odd member (not 8-byte aligned: the scalar kernels must take over) — through the raw
         # C ABI, members outside the range untouched
@@ -404,16 +514,16 @@ def test_checkpoint_state_dict_roundtrip(gpu, tmp_path):
     E = emi.rcp_like_emissions(n_steps, 3)
     kw = dict(collect_stats=True, hist=(-1.0, 4.0, 512))
     whole = _engine(p, N, E, **kw)
-    whole.run(mode="tiled")
+    whole.run(mode="fused")
     first = _engine(p, N, E, **kw)
-    first.run(0, 33, mode="tiled")
+    first.run(0, 33, mode="fused")
     ck = first.state_dict(include_outputs=True)
     assert ck["t_next"] == 33
     np.savez(tmp_path / "ck.npz", **ck)
     second = _engine(p, N, E, **kw)
     second.load_state_dict(dict(np.load(tmp_path / "ck.npz")))
     assert second.t_next == 33
-    second.run(second.t_next, n_steps, mode="tiled")
+    second.run(second.t_next, n_steps, mode="fused")
     torch.cuda.synchronize()
     assert torch.equal(second.R, whole.R) and torch.equal(second.S, whole.S)
     # the checkpoint carries what the run had accumulated: ALL rows, moments and histograms equal an uninterrupted run
@@ -426,7 +536,7 @@ def test_checkpoint_state_dict_roundtrip(gpu, tmp_path):
     assert small["_step_sums"].shape == (n_steps, 5) and small["_step_sums_valid"].tolist() == [True] * 33 + [False] * 57
     third = _engine(p, N, E, **kw)
     third.load_state_dict(small)
-    third.run(33, n_steps, mode="tiled", k_steps=5)                      # another launch shape after the resume
+    third.run(33, n_steps, mode="per_step")                              # another launch shape after the resume
     torch.cuda.synchronize()
     assert torch.equal(third.T_hist, whole.T_hist) and torch.equal(third.T[33:], whole.T[33:])
     assert int(third.T[:33].abs().sum()) == 0                            # rows of the first leg were not carried
@@ -442,19 +552,18 @@ def test_checkpoint_state_dict_roundtrip(gpu, tmp_path):
 
 
 def test_reset_and_reload_clear_the_run_accumulators(gpu):
-    """T_hist accumulates and the streamed pipeline leaves per-step moments behind: reset_state() and a state-only
-    load_state_dict() must clear both, or a second run double-counts its histogram and reads the first run's moments."""
+    """T_hist accumulates and a checkpoint's summaries leave folded per-step moments behind: reset_state() and a state-only
+    load_state_dict() must clear both, or a second run double-counts its histogram and reads another run's moments."""
     N, n_steps = 3000, 40
     p = prm.sample_ensemble(prm.default_params("multigas"), N)
     E = emi.rcp_like_emissions(750, 3)[240:240 + n_steps]
-    eng = _engine(p, N, E, store_concentrations=False, collect_stats=True, hist=(-1.0, 4.0, 256), hist_ring_steps=8,
-                  hist_ring="T")
-    eng.run(mode="fused")                                                # streamed T ring: moments come from the histogram pass
+    eng = _engine(p, N, E, store_concentrations=False, collect_stats=True, hist=(-1.0, 4.0, 256), hist_ring_steps=8)
+    eng.run(mode="fused")                                                # streamed bin ring; moments from the wave records
     torch.cuda.synchronize()
     hist1, sums1 = eng.T_hist.clone(), eng.stats_sums().clone()
-    assert eng._step_sums_valid.all() and hist1.sum(1).tolist() == [N] * n_steps
+    assert hist1.sum(1).tolist() == [N] * n_steps and not eng._step_sums_valid.any()
     eng.reset_state()
-    assert int(eng.T_hist.sum()) == 0 and not eng._step_sums_valid.any()
+    assert int(eng.T_hist.sum()) == 0 and eng.t_next == 0
     eng.run(mode="fused")
     torch.cuda.synchronize()
     assert torch.equal(eng.T_hist, hist1) and torch.equal(eng.stats_sums(), sums1)       # not doubled
@@ -463,21 +572,24 @@ def test_reset_and_reload_clear_the_run_accumulators(gpu):
     other.run(0, 11, mode="fused")
     eng.load_state_dict(other.state_dict(include_outputs=False))
     assert int(eng.T_hist.sum()) == 0 and not eng._step_sums_valid.any() and eng.t_next == 11
-    eng.run(11, n_steps, mode="tiled")
+    eng.run(11, n_steps, mode="per_step")
     torch.cuda.synchronize()
     want = _engine(p, N, E, store_concentrations=False, collect_stats=True)
     want.load_state_dict(other.state_dict(include_outputs=False))
-    want.run(11, n_steps, mode="per_step")
+    want.run(11, n_steps, mode="fused")
     torch.cuda.synchronize()
     a, b = eng.stats_sums(11, n_steps), want.stats_sums(11, n_steps)
     assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]) and torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-13, atol=0)
     assert not torch.allclose(a[:, 1], sums1[11:, 1], rtol=1e-6)                        # and NOT the first run's moments
-    # a run that overwrites streamed steps with wave-record steps invalidates the pass moments of exactly those steps
+    # folded moments a checkpoint brought stay valid until a run writes wave records for exactly those steps
     eng.reset_state()
     eng.run(mode="fused")
-    eng.run(16, 24, mode="tiled")
-    assert eng._step_sums_valid[:16].all() and not eng._step_sums_valid[16:24].any() and eng._step_sums_valid[24:].all()
-    for e in (eng, other, want):
+    fresh = _engine(p, N, E, store_concentrations=False, collect_stats=True, hist=(-1.0, 4.0, 256), hist_ring_steps=8)
+    fresh.load_state_dict(eng.state_dict())                              # "summaries": T_hist + folded sums, no wave records
+    assert fresh._step_sums_valid.all() and torch.equal(fresh.stats_sums(), eng.stats_sums())
+    fresh.run(16, 24, mode="per_step")
+    assert fresh._step_sums_valid[:16].all() and not fresh._step_sums_valid[16:24].any() and fresh._step_sums_valid[24:].all()
+    for e in (eng, other, want, fresh):
         e.close()
 
 
@@ -691,9 +803,9 @@ def test_on_device_stats_match_trajectory(gpu, mode, N):
 @pytest.mark.parametrize("dtype,N", [("f64", 1), ("f64", 1023), ("f64", 1024), ("f64", 1025), ("f64", 70_001),
                                      ("f32", 300_007)])
 def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
-    """the tiled kernel accumulates T_hist[step][bin] INSIDE the time loop (LDS-privatised,
-    non-zero bins flushed).  (i) bit for bit the histogram fiveeq_hist_rows_* makes of the stored T rows, at ragged
-    sizes, with outliers in the edge bins; (ii) C, T, R, S and the per-wave moments identical to the fused kernel's;
+    """T_hist[step][bin] of EVERY step without a stored trajectory, through the ring of bin indices
+    the stepping kernel writes.  (i) bit for bit the histogram fiveeq_hist_rows_* makes of the stored T rows, at ragged
+    sizes, with outliers in the edge bins; (ii) C, T, R, S and the per-wave moments identical to the plain fused kernel's;
     (iii) a run that stores NOTHING gives the same histogram; (iv) percentiles read off it lie within one bin
     width of np.percentile of the ORACLE's T."""
     n_steps = 90
@@ -705,34 +817,30 @@ def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
     ref = _engine(p, N, E, dtype=td, collect_stats=True)
     ref.run(mode="fused")
     eng = _engine(p, N, E, dtype=td, collect_stats=True, hist=(lo, hi, nb))
-    assert eng.tile_steps() >= 8
-    eng.run(mode="tiled")
-    bare = _engine(p, N, E, dtype=td, store_trajectory=False, hist=(lo, hi, nb))
-    bare.run(0, 40, mode="tiled", k_steps=3)                  # ragged tiles, resumed
-    bare.run(40, n_steps, mode="tiled")
+    eng.run(mode="fused")
+    bare = _engine(p, N, E, dtype=td, store_trajectory=False, hist=(lo, hi, nb), hist_ring_steps=3)
+    bare.run(0, 40, mode="fused")                             # ragged chunks, resumed
+    bare.run(40, n_steps, mode="per_step")
     strm = _engine(p, N, E, dtype=td, output_steps=[3, 50, n_steps - 1], store_concentrations=False, collect_stats=True,
                    hist=(lo, hi, nb), hist_ring_steps=7)      # streamed pipeline: fused kernel + ring + second stream
     strm.run(0, 33, mode="fused")
     strm.hist_ring_steps = 11                                  # changed between runs: the ring is rebuilt, not overrun
     strm.run(33, n_steps, mode="fused")                        # resumed mid-chunk
     pers = _engine(p, N, E, dtype=td, output_steps=[3, 50], store_concentrations=False, collect_stats=True,
-                   hist=(lo, hi, nb), chunk_members=256 if N > 600 else 0)     # per-step kernel + histogram of each row
+                   hist=(lo, hi, nb), chunk_members=256 if N > 600 else 0)     # per-step kernel + the ring strip
     pers.run(mode="per_step")
     torch.cuda.synchronize()
     for name in ("C", "T", "R", "S", "T_stats"):
         assert torch.equal(getattr(eng, name), getattr(ref, name)), name
     want = ref.T_histogram(lo, hi, nb)
     assert torch.equal(pers.T_hist, want) and torch.equal(pers.T, ref.T[[3, 50]])
-    # the per-step kernel folds a wave's moments with the DPP ladder, the fused/tiled kernels with the LDS transpose:
+    # the per-step kernel folds a wave's moments with the DPP ladder, the fused kernel with the LDS transpose:
     # same numbers, different summation order (min/max exact, sums to rounding)
     assert torch.equal(pers.T_stats[..., 2:], ref.T_stats[..., 2:])
     assert torch.allclose(pers.T_stats[..., :2], ref.T_stats[..., :2], rtol=1e-12, atol=0)
     assert torch.equal(eng.T_hist, want)
     assert torch.equal(strm.T_hist, want) and torch.equal(strm.T, ref.T[[3, 50, n_steps - 1]])
-    assert torch.equal(strm.R, ref.R)
-    # the streamed pipeline takes its moments from the histogram pass (same numbers, another summation order)
-    a, b = strm.stats_sums(), ref.stats_sums()
-    assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]) and torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-12, atol=0)
+    assert torch.equal(strm.R, ref.R) and torch.equal(strm.stats_sums(), ref.stats_sums())
     assert torch.equal(bare.T_hist, want) and torch.equal(bare.R, ref.R)
     assert eng.T_hist.sum(1).tolist() == [N] * n_steps
     assert int(want[-1, 0]) + int(want[-1, -1]) > 0 or N < 100           # the edge bins are exercised
@@ -740,7 +848,7 @@ def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
     if dtype == "f64" and N >= 1000:
         from fiveeqscm_amd.distributed import histogram_percentiles
         wide = _engine(p, N, E, store_trajectory=False, hist=(-2.0, 12.0, nb))
-        wide.run(mode="tiled")
+        wide.run(mode="fused")
         torch.cuda.synchronize()
         T_or = c_oracle.run(E, p, N, n_threads=4)["T"]
         hp, tot = histogram_percentiles(wide.T_hist, -2.0, 12.0, (5.0, 50.0, 95.0))
@@ -753,7 +861,7 @@ def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
 
 def test_randomized_launch_shapes_and_histogram_specs(gpu):
     """60 random combinations of ensemble size (around the 64 / 256 / 1024 block edges), step sub-ranges, steps per
-    launch, dtype, layout and histogram specification: tiled / K-step / streamed results must equal the fused kernel's
+    launch, dtype, layout and histogram specification: K-step / small / streamed results must equal the fused kernel's
     bit for bit, and every in-loop histogram the histogram of the stored rows."""
     rng = np.random.default_rng(2026)
     edges = [1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 2047, 2049, 3000, 5000]
@@ -774,24 +882,27 @@ def test_randomized_launch_shapes_and_histogram_specs(gpu):
         state = ref.state_dict(include_outputs=False)
         ref.run(t0, t1, mode="fused")
         want_hist = ref.T_histogram(lo, hi, nb, rows=list(range(t0, t1)))
-        k_tile = int(rng.integers(0, 9))
-        for mode, k in (("tiled", k_tile), ("fused", None), ("per_step", None), ("ksteps", int(rng.integers(1, 20)))):
-            eng = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=True,
-                          hist=None if mode == "ksteps" else (lo, hi, nb), hist_ring_steps=int(rng.integers(1, 12)),
-                          hist_ring=("bins", "T")[case % 2])
+        forms = [("fused", None), ("per_step", None), ("ksteps", int(rng.integers(1, 20)))]
+        if G == 1:                                                    # the small-ensemble kernel: single-gas layouts, no statistics
+            forms += [("small", 1), ("small", 4)]
+        for mode, k_use in forms:
+            plain = mode in ("ksteps", "small")                       # forms that do not fill T_hist
+            eng = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=mode != "small",
+                          hist=None if plain else (lo, hi, nb), hist_ring_steps=int(rng.integers(1, 12)),
+                          small_lanes=k_use if mode == "small" else "auto")
             eng.load_state_dict(state)
-            k_use = min(k, eng.tile_steps()) if mode == "tiled" else k
-            eng.run(t0, t1, mode=mode, k_steps=k_use)
+            eng.run(t0, t1, mode=mode, k_steps=None if mode == "small" else k_use)
             torch.cuda.synchronize()
             what = (case, N, n_steps, t0, t1, kind, td, nb, mode, k_use)
             assert torch.equal(eng.R, ref.R) and torch.equal(eng.S, ref.S), what
             assert torch.equal(eng.T[t0:t1], ref.T[t0:t1]), what
-            if mode != "ksteps":
+            if not plain:
                 assert torch.equal(eng.T_hist[t0:t1], want_hist), what
                 assert int(eng.T_hist[:t0].sum()) == 0 and int(eng.T_hist[t1:].sum()) == 0, what
-            a, b = eng.stats_sums(t0, t1), ref.stats_sums(t0, t1)
-            assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]), what
-            assert torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-11, atol=1e-9), what
+            if mode != "small":
+                a, b = eng.stats_sums(t0, t1), ref.stats_sums(t0, t1)
+                assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]), what
+                assert torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-11, atol=1e-9), what
             eng.close()
         ref.close()
 
@@ -804,36 +915,19 @@ def test_runs_are_reproducible_bit_for_bit(gpu):
     E = emi.rcp_like_emissions(750, 3)[260:260 + n_steps]
     outs = []
     for rep in range(3):
-        for mode in ("fused", "tiled", "per_step"):
+        for mode in ("fused", "per_step"):
             eng = _engine(p, N, E, store_concentrations=False, output_steps=[10, 59], collect_stats=True,
                           hist=(-1.0, 5.0, 4096), hist_ring_steps=16)
             eng.run(mode=mode)
             torch.cuda.synchronize()
             outs.append((mode, eng.T_hist.clone(), eng.T.clone(), eng.R.clone(), eng.stats_sums().clone()))
             eng.close()
-    for mode in ("fused", "tiled", "per_step"):
+    for mode in ("fused", "per_step"):
         same = [o for o in outs if o[0] == mode]
         for other in same[1:]:
             for a, b in zip(same[0][1:], other[1:]):
                 assert torch.equal(a, b), mode
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][1], outs[2][1])      # and the same histogram in every mode
-
-
-def test_in_loop_histogram_survives_many_blocks_per_workgroup(gpu):
-    """More than 63 member blocks per persistent workgroup (one workgroup per CU: > CUs x 63 x 1024 = 16.5M members)
-    forces the intermediate LDS flush of the packed 16-bit counters; a 1-bin histogram concentrates every member
-    of a workgroup in ONE counter — the worst case for overflow.  Parameters are drawn on the device
-    (sample_ensemble_shard), so nothing of size N touches the host."""
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    N, n_steps = cus * 64 * 1024 + 5000, 5
-    p = prm.sample_ensemble_shard(prm.default_params("co2"), N, device="cuda:0", dtype=torch.float32)
-    E = emi.rcp_like_emissions(n_steps, 1) + 3.0
-    for nb in (1, 2, 4096):
-        eng = _engine(p, N, E, dtype=torch.float32, store_trajectory=False, hist=(-1.0, 1.0, nb))
-        eng.run(mode="tiled")
-        torch.cuda.synchronize()
-        assert eng.T_hist.sum(1).tolist() == [N] * n_steps, nb
-        del eng
+    assert torch.equal(outs[0][1], outs[1][1])                                               # and the same histogram in both modes
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -1237,39 +1331,10 @@ def test_percentile_selection_on_device_rows(gpu, dtype):
     np.testing.assert_allclose(one["percentiles"].cpu().numpy(), np.percentile(xs, pct, axis=1).T, rtol=1e-13, atol=0)
 
 
-def test_tiled_kernel_lds_limit_is_set_once_per_instantiation(gpu):
-    """The tiled kernel's dynamic-LDS limit is a property of (kernel instantiation, device): it is raised once, to what
-    the device allows, and not per launch; the LDS size itself is read from the device (160 KiB on MI355X)."""
-    from fiveeqscm_amd import _capi
-    lib = _capi.load()
-    assert lib.fiveeq_tile_lds_bytes() == 160 * 1024
-    assert lib.fiveeq_tile_steps_f64(4096) == 11 and lib.fiveeq_tile_steps_f32(4096) == 11
-    N, n_steps = 2000, 66
-    E = emi.rcp_like_emissions(750, 3)[250:250 + n_steps]
-    p = prm.sample_ensemble(prm.default_params("multigas"), N)
-    counts = []
-    for layout_case in range(2):
-        for rep in range(3):
-            eng = _engine(p, N, E, dtype=(torch.float64, torch.float32)[layout_case], store_trajectory=False,
-                          hist=(-1.0, 5.0, 4096))
-            eng.run(mode="tiled")                          # 6 launches of 11 steps, 88 KiB of histogram in LDS each
-            torch.cuda.synchronize()
-            assert eng.T_hist.sum(1).tolist() == [N] * n_steps
-            counts.append(lib.fiveeq_tile_attr_calls())
-            eng.close()
-    # (an earlier test of this session may already have prepared either instantiation: at most one new call each)
-    assert counts[0] == counts[1] == counts[2] and counts[3] == counts[4] == counts[5] and counts[3] - counts[0] in (0, 1)
-    small = _engine(p, N, E, store_trajectory=False, hist=(-1.0, 5.0, 512))
-    small.run(mode="tiled", k_steps=32)                    # 32 x 1 KiB: under 48 KiB, no attribute needed
-    torch.cuda.synchronize()
-    assert lib.fiveeq_tile_attr_calls() == counts[-1]
-    small.close()
-
-
-def test_bin_index_ring_equals_the_T_ring_and_keeps_stored_concentrations(gpu):
-    """The default streamed form writes 2-byte bin indices from inside the fused kernel: its T_hist must equal the T ring's
-    and the histogram of stored rows bit for bit (same bin rule), the model results must not notice it, the moments come
-    from the kernel's wave records — and, unlike the T ring, it coexists with stored C rows.  Ragged sizes (the last packed
+def test_bin_index_ring_equals_the_histogram_of_stored_rows_and_keeps_stored_concentrations(gpu):
+    """The streamed form writes 2-byte bin indices from inside the fused kernel: its T_hist must equal the histogram of stored
+    rows bit for bit (same bin rule), the model results must not notice it, the moments come from the kernel's wave
+    records, and it coexists with stored C rows.  Ragged sizes (the last packed
     lane holds one member; rows that are not 8-byte aligned take the pass's narrow path), NaN-free edge bins in use."""
     rng = np.random.default_rng(3)
     for N, td in ((1, torch.float64), (2, torch.float32), (1001, torch.float64), (1001, torch.float32), (4098, torch.float32),
@@ -1280,14 +1345,10 @@ def test_bin_index_ring_equals_the_T_ring_and_keeps_stored_concentrations(gpu):
         lo, hi, nb = 0.2, 1.4, int(rng.choice([7, 512, 4096]))          # tight range: both edge bins collect outliers
         a = _engine(p, N, E, dtype=td, collect_stats=True, hist=(lo, hi, nb), hist_ring_steps=int(rng.integers(1, 9)))
         a.run(mode="fused")
-        b = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=True, hist=(lo, hi, nb), hist_ring="T",
-                    hist_ring_steps=5)
-        b.run(mode="fused")
         ref = _engine(p, N, E, dtype=td, collect_stats=True)
         ref.run(mode="fused")
         torch.cuda.synchronize()
-        assert a.hist_ring == "bins" and a.C is not None
-        assert torch.equal(a.T_hist, b.T_hist) and torch.equal(a.T_hist, ref.T_histogram(lo, hi, nb)), (N, td, nb)
+        assert a.C is not None and torch.equal(a.T_hist, ref.T_histogram(lo, hi, nb)), (N, td, nb)
         assert a.T_hist.sum(1).tolist() == [N] * n_steps
         assert N < 1000 or (int(a.T_hist[:, 0].sum()) > 0 and int(a.T_hist[:, -1].sum()) > 0)      # both edge bins in use
         for name in ("C", "T", "R", "S", "T_stats"):
@@ -1304,7 +1365,7 @@ def test_bin_index_ring_equals_the_T_ring_and_keeps_stored_concentrations(gpu):
             assert torch.equal(getattr(c, name), getattr(ref, name)), (N, td, name, "per_step")
         sc, sr = c.stats_sums(), ref.stats_sums()
         assert torch.equal(sc[:, [0, 3, 4]], sr[:, [0, 3, 4]]) and torch.allclose(sc[:, 1:3], sr[:, 1:3], rtol=1e-13, atol=1e-11)
-        for e in (a, b, c, ref):
+        for e in (a, c, ref):
             e.close()
 
 
@@ -1417,7 +1478,7 @@ def test_fused_span_relaunch_is_bit_identical(gpu, monkeypatch):
 
 def test_auto_with_histograms_picks_what_the_measured_table_says(gpu):
     """profiles/r04/auto_hist_table.json: on a launch-bound ensemble the streamed pipeline (mode 'fused') fills T_hist 2-4x
-    faster than per-step + bins and than the tiled kernel at the auto K, so that is what mode='auto' resolves to on an
+    faster than per-step + bins (and than round 4's tiled kernel at the auto K), so that is what mode='auto' resolves to on an
     engine with hist=; a bandwidth-bound ensemble keeps the per-step kernel (the north-star form).  Whatever it picks, the
     results are those of the explicit per-step run, bit for bit."""
     import json
@@ -1528,8 +1589,8 @@ def test_per_step_histograms_use_a_one_slot_bin_ring(gpu):
 
 def test_random_sequences_of_segments_modes_and_checkpoints(gpu):
     """30 random runs cut into 2-5 consecutive segments, every segment in another launch shape (per-step, fused, K-step,
-    tiled, graph replay, auto — with hist= the forms that fill T_hist), one checkpoint somewhere on the way restored into a
-    FRESH engine (reduced outputs or raw buffers), fp64 / fp32, bin-index or T ring, stored concentrations or not: state, stored
+    graph replay, auto — with hist= the forms that fill T_hist), one checkpoint somewhere on the way restored into a
+    FRESH engine (reduced outputs or raw buffers), fp64 / fp32, stored concentrations or not: state, stored
     rows, histograms and per-step moments at the end must be those of ONE per-step run of the whole range."""
     rng = np.random.default_rng(404)
     for case in range(30):
@@ -1538,9 +1599,9 @@ def test_random_sequences_of_segments_modes_and_checkpoints(gpu):
         kind, G = (("multigas", 3), ("co2", 1))[int(rng.integers(0, 2))]
         td = (torch.float64, torch.float32)[int(rng.integers(0, 2))]
         with_hist = bool(rng.integers(0, 2))
-        ring = ("bins", "T")[int(rng.integers(0, 2))]
-        store_c = bool(rng.integers(0, 2)) and not (with_hist and ring == "T")          # a T ring carries T only
-        kw = dict(dtype=td, store_concentrations=store_c, collect_stats=True, hist_ring=ring,
+        ring = int(rng.integers(0, 2))                                                   # (kept: the stream of random numbers)
+        store_c = bool(rng.integers(0, 2))
+        kw = dict(dtype=td, store_concentrations=store_c, collect_stats=True,
                   hist=(-0.5, float(rng.uniform(2.0, 6.0)), int(rng.choice([64, 1000, 4096]))) if with_hist else None,
                   hist_ring_steps=int(rng.integers(2, 20)))
         p = prm.sample_ensemble(prm.default_params(kind), N, seed=1000 + case)
@@ -1548,7 +1609,7 @@ def test_random_sequences_of_segments_modes_and_checkpoints(gpu):
         ref = _engine(p, N, E, **kw)
         ref.run(mode="per_step")
         cuts = sorted(set([0, n_steps] + [int(v) for v in rng.integers(1, n_steps, size=int(rng.integers(1, 5)))]))
-        modes = ["per_step", "fused", "tiled", "auto"] if with_hist else ["per_step", "fused", "ksteps", "tiled", "graph", "auto"]
+        modes = ["per_step", "fused", "auto"] if with_hist else ["per_step", "fused", "ksteps", "graph", "auto"]
         ck_at = int(rng.integers(1, len(cuts) - 1)) if len(cuts) > 2 else None            # checkpoint BEFORE this segment
         raw = bool(rng.integers(0, 2))
         eng, first_row, log = _engine(p, N, E, **kw), 0, []
@@ -1561,9 +1622,7 @@ def test_random_sequences_of_segments_modes_and_checkpoints(gpu):
                 first_row = 0 if raw else cuts[i]                                     # "summaries" do not carry stored rows
                 log.append(("checkpoint", "raw" if raw else "summaries", cuts[i]))
             mode = modes[int(rng.integers(0, len(modes)))]
-            k = int(rng.integers(1, 12)) if mode in ("ksteps", "tiled") else None
-            if mode == "tiled":
-                k = min(k, eng.tile_steps())
+            k = int(rng.integers(1, 12)) if mode == "ksteps" else None
             eng.run(cuts[i], cuts[i + 1], mode=mode, k_steps=k)
             log.append((mode, k, cuts[i], cuts[i + 1]))
         torch.cuda.synchronize()

@@ -5,16 +5,16 @@
 # committed bench line was produced with an older valu.json / traffic.json than the one committed beside it.
 # rocprofv3 is always given `python3 script` directly after `--`; --pmc passes carry --kernel-trace only.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/${TAG}k; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 cp $R/profiles/valu.json $OUT/valu.json
 SQA="SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 SQB="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM"
 SQC="SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_CVT"
-for S in a b c; do eval C=\$SQ$(echo $S | tr a-z A-Z); timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_sq${S}_fused32 -- python3 $R/tools/pmc_workload_fused.py 4000000 f32 96 8 > $OUT/pmc_sq${S}_fused32.log 2>&1; echo "fused32 $S"; done
-python3 $R/tools/pmc_valu.py $OUT/sq_counters_f32_4M.csv $OUT/valu.json 96 4000000 8 $OUT/pmc_sqa_fused32 $OUT/pmc_sqb_fused32 $OUT/pmc_sqc_fused32 > /dev/null
+for S in a b c; do eval C=\$SQ$(echo $S | tr a-z A-Z); timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_sq${S}_fused32 -- python3 $R/tools/pmc_workload_fused.py 4000000 f32 96 > $OUT/pmc_sq${S}_fused32.log 2>&1; echo "fused32 $S"; done
+python3 $R/tools/pmc_valu.py $OUT/sq_counters_f32_4M.csv $OUT/valu.json 96 $OUT/pmc_sqa_fused32 $OUT/pmc_sqb_fused32 $OUT/pmc_sqc_fused32 > /dev/null
 for S in a c; do eval C=\$SQ$(echo $S | tr a-z A-Z); timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_sq${S}_step32 -- python3 $R/tools/pmc_workload.py 4000000 multigas f32 > $OUT/pmc_sq${S}_step32.log 2>&1; echo "step32 $S"; done
-python3 $R/tools/pmc_valu.py $OUT/sq_counters_step_f32_4M.csv $OUT/valu.json 1 4000000 1 $OUT/pmc_sqa_step32 $OUT/pmc_sqc_step32 > /dev/null
+python3 $R/tools/pmc_valu.py $OUT/sq_counters_step_f32_4M.csv $OUT/valu.json 1 $OUT/pmc_sqa_step32 $OUT/pmc_sqc_step32 > /dev/null
 cp $OUT/valu.json $R/profiles/valu.json
 cd $R
 python3 bench.py > $OUT/bench_config3.json 2> $OUT/bench_config3.err; echo bench1
@@ -23,7 +23,8 @@ python3 bench.py --no-cpu-baseline --mode fused > $OUT/bench_config3_fused.json 
 python3 bench.py --no-cpu-baseline --mode graph > $OUT/bench_config3_graph.json 2>/dev/null; echo bench4
 python3 bench.py --no-cpu-baseline --workload config2 > $OUT/bench_config2_per_step.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --workload config2 --mode graph > $OUT/bench_config2_graph.json 2>/dev/null
-python3 bench.py --no-cpu-baseline --workload config2 --mode auto > $OUT/bench_config2_auto_ksteps.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --workload config2 --mode auto > $OUT/bench_config2_auto.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --workload config2 --mode ksteps > $OUT/bench_config2_ksteps.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --workload config2 --mode fused > $OUT/bench_config2_fused.json 2>/dev/null; echo bench8
 python3 bench.py --no-cpu-baseline --workload config4 > $OUT/bench_config4_per_gpu_shard.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --workload config5 --dtype f32 --steps 300 > $OUT/bench_config5_f32_per_gpu_shard.json 2>/dev/null

@@ -3,7 +3,7 @@
 # tools/collect_final_bench_lines.sh): copies what is judged from the scratch gpurun_out/<tag>/ into profiles/<round>/ (and the
 # two counter files bench.py reads into profiles/).   Usage: bash tools/copy_collected.sh [r04|r04k]
 set -u
-TAG=${1:-r04}; S=gpurun_out/$TAG; D=profiles/${TAG%k}; mkdir -p $D
+TAG=${1:-r05}; S=gpurun_out/$TAG; D=profiles/${TAG%k}; mkdir -p $D
 for f in $S/bench_*.json $S/sq_counters_*.csv; do [ -f "$f" ] && cp "$f" $D/; done
 # the tables come from collect_profiles.sh only; *_ab.txt are hand-labelled A/B records: never overwritten from scratch
 [ "$TAG" = "${TAG%k}" ] && for f in $S/*.txt; do case "$f" in *_ab.txt) ;; *) [ -f "$f" ] && cp "$f" $D/;; esac; done
@@ -17,4 +17,5 @@ pick() { ls -t $S/$1/*/*$2 2>/dev/null | head -1; }     # the newest: gpurun mer
 k=$(pick trace _kernel_stats.csv); [ -n "$k" ] && cp "$k" $D/kernel_stats_bench_config3.csv
 k=$(pick trace _domain_stats.csv); [ -n "$k" ] && cp "$k" $D/domain_stats_bench_config3.csv
 k=$(pick trace_config5_demo _kernel_stats.csv); [ -n "$k" ] && cp "$k" $D/kernel_stats_config5_demo_streamed_pipeline.csv
+k=$(pick trace_config2 _kernel_stats.csv); [ -n "$k" ] && cp "$k" $D/kernel_stats_bench_config2_auto.csv
 ls $D | wc -l

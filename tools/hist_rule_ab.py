@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box A/B of library builds on the in-loop histogram forms at the config-5 shard (12.5M fp32 members, no trajectory,
-statistics on): stats-only fused, fused + streamed bin-index ring, tiled 4096 / 1024 bins, per-step + bin ring.
+statistics on): stats-only fused, fused + streamed bin-index ring, per-step + bin ring.
     python3 tools/hist_rule_ab.py default /tmp/fiveeq_variants/lib_X.so ...      (rounds alternate between the builds)"""
 import os
 import sys
@@ -20,8 +20,6 @@ E = emissions.rcp_like_emissions(STEPS, 3)
 p = params.sample_ensemble_shard(params.default_params("multigas"), N, device="cuda:0", dtype=torch.float32)
 CASES = [("fused stats-only", None, dict(mode="fused")),
          ("fused + bin ring 2x64, 4096 bins", 4096, dict(mode="fused")),
-         ("tiled 4096 bins (K=11)", 4096, dict(mode="tiled")),
-         ("tiled 1024 bins (K=46)", 1024, dict(mode="tiled")),
          ("per-step stats-only", None, dict(mode="per_step")),
          ("per-step + bin ring, 4096 bins", 4096, dict(mode="per_step"))]
 best = {}

@@ -1,10 +1,7 @@
 #!/usr/bin/env python3
 """Reduce rocprofv3 --pmc SQ_* passes to per-kernel means and to VALU wave-instructions per wave-step.
 
-    python tools/pmc_valu.py <summary.csv> <valu.json> <steps_per_fused_launch> <members> <tile_k_steps> <pass_dir> [...]
-
-(the tiled kernel is persistent: its SQ_WAVES are workgroup waves, not member waves, so its per-wave-step figure is
-total VALU / (ceil(members / 64) x tile_k_steps))
+    python tools/pmc_valu.py <summary.csv> <valu.json> <steps_per_fused_launch> <pass_dir> [...]
 
 summary.csv  : kernel, counter, dispatches, mean value per dispatch   (committed under profiles/<round>/)
 valu.json    : {"step:f64:4,1,1": {"valu_per_wave_step": ..., ...}, "fused:f64:4,1,1": {...}, ...}  (bench.py reads it)
@@ -24,10 +21,9 @@ import sys
 
 def main():
     out_csv, out_json, fused_steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    members, tile_k = int(sys.argv[4]), int(sys.argv[5])
     acc = collections.defaultdict(list)
     dur = collections.defaultdict(list)
-    for d in sys.argv[6:]:
+    for d in sys.argv[4:]:
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(path) as fh:
                 for row in csv.DictReader(fh):
@@ -51,7 +47,10 @@ def main():
     kernels = {k for k, _ in acc}
     for k in sorted(kernels):
         # fused_kernel<V, P0, P1, P2, INV, BINS>: the plain forward form only
-        m = re.match(r"fiveeq::(step|fused|tile)_kernel<(double|float2|float), (\d), (\d), (\d)((?:, (?:true|false))*)>", k)
+        ms = re.match(r"fiveeq::small_kernel<(double|float), (\d), (\d)>", k)       # <T, P0, lanes per member>: single-gas layouts
+        m = re.match(r"fiveeq::(step|fused)_kernel<(double|float2|float), (\d), (\d), (\d)((?:, (?:true|false))*)>", k)
+        if ms:
+            m = re.match(r"(small) (\w+) (\d) (0) (0)()", f"small {ms.group(1)} {ms.group(2)} 0 0")
         if not m or "true" in m.group(6):
             continue
         mean = lambda c: (sum(acc[(k, c)]) / len(acc[(k, c)])) if (k, c) in acc else None   # noqa: E731
@@ -60,10 +59,11 @@ def main():
             continue
         steps = 1 if m.group(1) == "step" else fused_steps
         per_wave = 128 if m.group(2) == "float2" else 64            # members of one wave: packed lanes carry two each
-        if m.group(1) == "tile":
-            steps, waves = tile_k, float(-(-members // per_wave))
         tag = {"double": "f64", "float": "f32", "float2": "f32x2"}[m.group(2)]
         key = f"{m.group(1)}:{tag}:{m.group(3)},{m.group(4)},{m.group(5)}"
+        if ms:
+            per_wave = 64 // int(ms.group(3))                       # a quad of lanes per member: 16 members per wave
+            key += f":{ms.group(3)}"
         rec = {"kernel": k, "valu_per_wave_step": valu / waves / steps, "members_per_wave": per_wave,
                "valu_per_member_step": valu / waves / steps / per_wave, "waves": waves, "steps_per_launch": steps,
                "dispatches": len(acc[(k, "SQ_INSTS_VALU")])}

@@ -19,7 +19,7 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 12_500_000
 p = params.sample_ensemble_shard(params.default_params("multigas"), N, device="cuda:0", dtype=torch.float32)
 E = emissions.rcp_like_emissions(750, 3)
 eng = EnsembleEngine(p, N, E, dtype=torch.float32, store_trajectory=False, collect_stats=True, hist=(-2.0, 12.0, 4096))
-eng.hist_ring, eng.hist_ring_steps, eng.hist_pass_stream = "bins", S, where
+eng.hist_ring_steps, eng.hist_pass_stream = S, where
 for rep in range(3):
     eng.reset_state()
     torch.cuda.synchronize()
