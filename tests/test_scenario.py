@@ -48,3 +48,44 @@ def test_malformed_files(tmp_path):
         read_emissions_csv(p)
     with pytest.raises(ValueError):
         write_emissions_csv(p, [2000, 2001], np.zeros((3, 3)))
+
+
+@pytest.mark.gpu
+def test_a_csv_scenario_through_the_engine(tmp_path):
+    """SURVEY section 8f-4 on the GPU: (i) the frozen 750-step scenario written in the RCP layout, read back and run from the
+    FILE gives the bits of the run from the ARRAY (C, T, state), 20k members x 3 gases; (ii) the RCP-layout fixture
+    tests/golden/rcp_layout_sample.csv (FossilCO2 + OtherCO2 summed, extra species ignored) through a 5-step run against the
+    oracle at <= 1e-10 relative — per-step and fused launches."""
+    import torch
+
+    from fiveeqscm_amd import params as prm
+    from fiveeqscm_amd.engine import EnsembleEngine
+    from oracle import fiveeq_oracle as npo
+    N = 20_000
+    p = prm.sample_ensemble_shard(prm.default_params("multigas"), N, device="cuda:0")
+    E = emi.rcp_like_emissions(750, 3)
+    path = tmp_path / "rcp_like.csv"
+    write_emissions_csv(path, 1765 + np.arange(750), E)
+    years, E_file = read_emissions_csv(path)
+    assert years[0] == 1765 and years[-1] == 2514
+    a = EnsembleEngine(p, N, E, device="cuda:0", output_steps=list(range(0, 750, 50)) + [749])
+    b = EnsembleEngine(p, N, E_file, device="cuda:0", output_steps=list(range(0, 750, 50)) + [749])
+    a.run(mode="per_step")
+    b.run(mode="fused")
+    torch.cuda.synchronize()
+    for name in ("C", "T", "R", "S"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.drive, b.drive)
+    a.close(), b.close()
+    _, E5 = read_emissions_csv(os.path.join(HERE, "golden", "rcp_layout_sample.csv"))
+    n = 777
+    ph = prm.sample_ensemble(prm.default_params("multigas"), n)
+    want = npo.run(E5, ph, n)
+    for mode in ("per_step", "fused"):
+        eng = EnsembleEngine(ph, n, E5, device="cuda:0")
+        eng.run(mode=mode)
+        torch.cuda.synchronize()
+        for name in ("C", "T"):
+            got = getattr(eng, name).cpu().numpy()
+            assert np.all(np.abs(got - want[name]) <= 1e-10 * np.abs(want[name]) + 1e-13), (mode, name)
+        eng.close()
