@@ -810,9 +810,9 @@ int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, d
 template <typename T>
 int math_probe(int32_t op, int64_t n, const T* x, T* y, void* stream) {
     const bool packed_op = sizeof(T) == 4 && op >= 8 && op <= 12;          // fp32: the packed twin on element pairs
-    const bool acc_op = sizeof(T) == 4 && (op == 18 || op == 20);           // fp32: the accurate log / reciprocal
+    const bool acc_op = sizeof(T) == 4 && (op == 16 || op == 18 || op == 20);   // fp32: the accurate expm1 / log / reciprocal
     if ((op < 0 || op > 4) && !packed_op && !acc_op)
-        return fail(FIVEEQ_E_INVALID, "op=%d outside 0..4 (fp32: also 8..12, 18, 20)", op);
+        return fail(FIVEEQ_E_INVALID, "op=%d outside 0..4 (fp32: also 8..12, 16, 18, 20)", op);
     if (n < 1) return fail(FIVEEQ_E_INVALID, "n=%lld must be >= 1", (long long)n);
     if (packed_op && (n & 1)) return fail(FIVEEQ_E_INVALID, "packed ops need an even n");
     if (!x || !y) return fail(FIVEEQ_E_INVALID, "NULL device pointer");

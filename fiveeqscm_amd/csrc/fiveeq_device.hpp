@@ -372,13 +372,30 @@ __device__ __forceinline__ float fe_log_acc(float x) {
     const float tail = __builtin_fmaf(dk, 9.0580006145e-06f, s * (hfsq + R));             // + k ln2_lo
     return __builtin_fmaf(dk, 6.9313812256e-01f, -((hfsq - tail) - f));                    // k ln2_hi - ...
 }
-// which reciprocal / logarithm gas_step() uses: the routines above by their lane type (every precision's default), or the
-// accurate fp32 forms
+// expm1(x), x <= 0, with the TWO-step Cody-Waite reduction (ln2 = hi + lo, hi with 12 zero low bits so that k hi is exact):
+// the fast form's single fma leaves 2^k |k| 2^-26 of ln2's own rounding error in every result with k != 0 — always with the
+// same sign, so over 750 steps it adds up where rounding noise averages out
+constexpr float F32_LN2_HI = 0.693145751953125f;
+constexpr float F32_LN2_LO = 1.42860682030941723212e-6f;
+__device__ __forceinline__ float fe_expm1_neg_acc(float x) {
+    x = fmaxf(x, -87.0f);
+    const float u = __builtin_fmaf(x, F32_LOG2E, F32_RINT_MAGIC);
+    const float k = u - F32_RINT_MAGIC;
+    float r = __builtin_fmaf(-k, F32_LN2_HI, x);
+    r = __builtin_fmaf(-k, F32_LN2_LO, r);
+    const float p = fe_expm1_reduced(r);
+    const float s = fe_exp2_from_magic(u);
+    return __builtin_fmaf(s, p, s - 1.0f);
+}
+// which expm1 / reciprocal / logarithm gas_step() uses: the routines above by their lane type (every precision's default),
+// or the accurate fp32 forms
 struct MathDefault {
+    template <typename V> static __device__ __forceinline__ V expm1(const V x) { return fe_expm1_neg(x); }
     template <typename V> static __device__ __forceinline__ V rcp(const V a) { return fe_rcp(a); }
     template <typename V> static __device__ __forceinline__ V log(const V x) { return fe_log(x); }
 };
 struct MathAccurateF32 {
+    static __device__ __forceinline__ float expm1(const float x) { return fe_expm1_neg_acc(x); }
     static __device__ __forceinline__ float rcp(const float a) { return fe_rcp_acc(a); }
     static __device__ __forceinline__ float log(const float x) { return fe_log_acc(x); }
 };
@@ -424,7 +441,7 @@ __device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, con
     // --- step_conc -----------------------------------------------------------------
     V em1[P];
 #pragma unroll
-    for (int i = 0; i < P; ++i) em1[i] = fe_expm1_neg(kg.ndt_over_tau[i] * inv_alpha);
+    for (int i = 0; i < P; ++i) em1[i] = M::expm1(kg.ndt_over_tau[i] * inv_alpha);
     V E;
     if constexpr (INV) {
         V num = V(0), den = V(0);
@@ -1856,7 +1873,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void math_probe_kernel(const int op, 
     if (i >= n) return;
     if constexpr (sizeof(T) == 4) {
         if (op >= 16) {                                      // the accurate fp32 forms (f32_math = 1): log, reciprocal
-            y[i] = op == 18 ? fe_log_acc(x[i]) : fe_rcp_acc(x[i]);
+            y[i] = op == 16 ? fe_expm1_neg_acc(x[i]) : (op == 18 ? fe_log_acc(x[i]) : fe_rcp_acc(x[i]));
             return;
         }
     }

@@ -379,7 +379,7 @@ int fiveeq_stream_copy_wide_f64(int64_t n, const double *src, double *dst, void 
  * pin each against a CPU libm to the ulp.  op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0, finite normal),
  * 3 sqrt (x > 0, finite normal), 4 reciprocal (x > 0, finite normal).  _f32 only: op + 8 evaluates the PACKED twin of
  * the primitive (two members per lane, fiveeq_set_f32_packing above) on the element pairs (x[2i], x[2i+1]), n even:
- * it must return the scalar routine's bits; op 18 / 20 = the ACCURATE log / reciprocal (f32_math = 1). */
+ * it must return the scalar routine's bits; op 16 / 18 / 20 = the ACCURATE expm1 / log / reciprocal (f32_math = 1). */
 int fiveeq_math_probe_f64(int32_t op, int64_t n, const double *x, double *y, void *stream);
 int fiveeq_math_probe_f32(int32_t op, int64_t n, const float *x, float *y, void *stream);
 
