@@ -55,7 +55,7 @@ class Model(ctypes.Structure):
         ("iirf_max", ctypes.c_double),
         ("dt", ctypes.c_double),
         ("n_gas", ctypes.c_int32),
-        ("f32_math", ctypes.c_int32),      # the _f32 entry points: 0 = fast, 1 = accurate (include/fiveeq.h)
+        ("reserved", ctypes.c_int32),
     ]
 
 

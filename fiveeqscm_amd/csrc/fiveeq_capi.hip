@@ -73,7 +73,6 @@ int check_model(const fiveeq_model* m) {
         if (!(m->d[j] > 0.0) || !std::isfinite(m->d[j]))
             return fail(FIVEEQ_E_INVALID, "d[%d]=%g must be finite and > 0", j, m->d[j]);
     if (std::isnan(m->iirf_max)) return fail(FIVEEQ_E_INVALID, "iirf_max is NaN");
-    if (m->f32_math != 0 && m->f32_math != 1) return fail(FIVEEQ_E_INVALID, "f32_math=%d must be 0 (fast) or 1 (accurate)", m->f32_math);
     for (int g = 0; g < m->n_gas; ++g) {
         const fiveeq_gas& gs = m->gas[g];
         if (gs.n_pools < 1 || gs.n_pools > FIVEEQ_MAX_POOLS)
@@ -151,7 +150,6 @@ struct RunArgs {
     int n_steps;
     double* stats;
     int packing;                 // the fp32 packing switch as this call found it
-    bool accurate;               // fp32 only: model->f32_math = 1, the accurate reciprocal / logarithm (one member per lane)
 };
 
 // the bin-index ring of the streamed histograms (fused_kernel<..., BINS = true>)
@@ -180,7 +178,7 @@ template <>
 struct LaneOf<float> {
     using Packed = float2v;
     static bool can_pack(const RunArgs<float>& a) {
-        if (!a.packing || a.accurate || a.n < 2 || (a.ld & 1)) return false;
+        if (!a.packing || a.n < 2 || (a.ld & 1)) return false;
         const uintptr_t bits = (uintptr_t)a.r | (uintptr_t)a.q | (uintptr_t)a.R | (uintptr_t)a.S | (uintptr_t)a.C_traj |
                                (uintptr_t)a.T_traj;
         return (bits & 7u) == 0;
@@ -195,25 +193,6 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st, const BinRing& br = 
     const int64_t blocks = (a.n + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_STEP_BLOCK);
-    if constexpr (std::is_same<T, float>::value) {
-        if (a.accurate) {
-            if (BINS) return fail(FIVEEQ_E_UNSUPPORTED, "f32_math = 1 (accurate) has no streamed-histogram form");
-            switch (a.code) {
-#define X(p0, p1, p2)                                                                                        \
-    case (p0) * 100 + (p1) * 10 + (p2):                                                                      \
-        hipLaunchKernelGGL((step_kernel<float, p0, p1, p2, false, MathAccurateF32>), grid, block, 0, st, a.km, a.drive,      \
-                           a.n_steps, t, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, br.ring,      \
-                           br.ring_rows, br.lo, br.inv_w, br.n_bins);                                        \
-        break;
-                FIVEEQ_LAYOUTS(X)
-#undef X
-                default:
-                    return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
-            }
-            HIP_TRY(hipGetLastError());
-            return FIVEEQ_OK;
-        }
-    }
     switch (a.code) {
 #define X(p0, p1, p2)                                                                             \
     case (p0) * 100 + (p1) * 10 + (p2):                                                           \
@@ -244,26 +223,6 @@ int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream
     const int64_t blocks = member_blocks(packed ? (a.n + 1) / 2 : a.n);
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_BLOCK);
-    if constexpr (std::is_same<T, float>::value) {
-        if (a.accurate) {
-            if (BINS || INV)
-                return fail(FIVEEQ_E_UNSUPPORTED, "f32_math = 1 (accurate) has no streamed-histogram and no concentration-driven form");
-            switch (a.code) {
-#define X(p0, p1, p2)                                                                                        \
-    case (p0) * 100 + (p1) * 10 + (p2):                                                                      \
-        hipLaunchKernelGGL((fused_kernel<float, p0, p1, p2, false, false, MathAccurateF32>), grid, block,    \
-                           FIVEEQ_FUSED_DYN_LDS, st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, \
-                           cumE, a.C_traj, a.T_traj, a.n_rows, a.stats, br.ring, br.ring_rows, br.lo, br.inv_w, br.n_bins);   \
-        break;
-                FIVEEQ_LAYOUTS(X)
-#undef X
-                default:
-                    return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
-            }
-            HIP_TRY(hipGetLastError());
-            return FIVEEQ_OK;
-        }
-    }
     switch (a.code) {
 #define X(p0, p1, p2)                                                                                  \
     case (p0) * 100 + (p1) * 10 + (p2):                                                                \
@@ -309,7 +268,6 @@ int make_args(RunArgs<T>& a, const fiveeq_model* m, int64_t n, int64_t ld, const
     a.n_steps = n_steps;
     a.stats = stats;
     a.packing = g_f32_packing.load(std::memory_order_relaxed);
-    a.accurate = std::is_same<T, float>::value && m->f32_math == 1;
     return FIVEEQ_OK;
 }
 
@@ -402,7 +360,6 @@ int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, nullptr)) return rc;
     const int widest = small_lanes(a.code);
     if (widest == 0) return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no small-ensemble kernel", a.code);
-    if (a.accurate) return fail(FIVEEQ_E_UNSUPPORTED, "f32_math = 1 (accurate) has no small-ensemble form");
     if (lanes == 0) lanes = widest;
     if (lanes != 1 && lanes != widest)
         return fail(FIVEEQ_E_INVALID, "lanes_per_member=%d: pool layout %03d takes 1%s", lanes, a.code, widest == 4 ? " or 4" : "");
@@ -511,12 +468,6 @@ const char* fiveeq_build_flags(void) {
 #endif
 #ifdef FIVEEQ_BIN_RULE_F64
            " FIVEEQ_BIN_RULE_F64"
-#endif
-#ifdef FIVEEQ_RING_NT_LOAD
-           " FIVEEQ_RING_NT_LOAD"
-#endif
-#ifdef FIVEEQ_RING_NT_STORE
-           " FIVEEQ_RING_NT_STORE"
 #endif
 #if FIVEEQ_FUSED_CHUNK != 125
            " FIVEEQ_FUSED_CHUNK=" FIVEEQ_STR(FIVEEQ_FUSED_CHUNK)
@@ -810,9 +761,7 @@ int hist_rows(int32_t n_rows, int64_t n, int64_t ld, const T* rows, double lo, d
 template <typename T>
 int math_probe(int32_t op, int64_t n, const T* x, T* y, void* stream) {
     const bool packed_op = sizeof(T) == 4 && op >= 8 && op <= 12;          // fp32: the packed twin on element pairs
-    const bool acc_op = sizeof(T) == 4 && (op == 16 || op == 18 || op == 20);   // fp32: the accurate expm1 / log / reciprocal
-    if ((op < 0 || op > 4) && !packed_op && !acc_op)
-        return fail(FIVEEQ_E_INVALID, "op=%d outside 0..4 (fp32: also 8..12, 16, 18, 20)", op);
+    if ((op < 0 || op > 4) && !packed_op) return fail(FIVEEQ_E_INVALID, "op=%d outside 0..4 (fp32: also 8..12)", op);
     if (n < 1) return fail(FIVEEQ_E_INVALID, "n=%lld must be >= 1", (long long)n);
     if (packed_op && (n & 1)) return fail(FIVEEQ_E_INVALID, "packed ops need an even n");
     if (!x || !y) return fail(FIVEEQ_E_INVALID, "NULL device pointer");

@@ -342,64 +342,6 @@ __device__ __forceinline__ float2v fe_sqrt(float2v x) {
     return float2v{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
 }
 
-// ---- the ACCURATE fp32 forms (fiveeq_model.f32_math = 1) ----------------------------------------------------------
-// Round 3 replaced the fp32 reciprocal's Newton step and the fdlibm-style fp32 logarithm by the bare hardware instructions
-// (v_rcp_f32, v_log_f32 x ln2 in two parts): -24 % on the fused fp32 kernel, for a factor 2.4 on the worst relative error of
-// C against 50-digit arithmetic (1.2e-6 -> 2.9e-6 over the 24 golden members; T 1.1e-5 -> 1.7e-5).  That trade is the
-// default; a caller who wants the digits back sets f32_math = 1 and the fp32 entry points run these forms instead, one
-// member per lane (no packed twins: this is not the fast path).
-__device__ __forceinline__ float fe_rcp_acc(float a) {
-    const float y = __builtin_amdgcn_rcpf(a);                // v_rcp_f32 (1 ulp) + one Newton step: <= 0.5 ulp
-    return __builtin_fmaf(y, __builtin_fmaf(-a, y, 1.0f), y);
-}
-// ln(x), fdlibm's scheme cut for fp32 (see fe_log(double)): frexp, s = f / (2 + f), degree-4 polynomial in s^2, k ln2 in
-// hi / lo parts: < 1 ulp over the model's range
-__device__ __forceinline__ float fe_log_acc(float x) {
-    float m = __builtin_amdgcn_frexp_mantf(x);
-    int k = __builtin_amdgcn_frexp_expf(x);
-    const bool low = m < 0.70710678118654752440f;
-    m = low ? m + m : m;
-    k = low ? k - 1 : k;
-    const float dk = (float)k;
-    const float f = m - 1.0f;
-    const float s = f * fe_rcp_acc(2.0f + f);
-    const float z = s * s;
-    const float w = z * z;
-    const float t1 = w * __builtin_fmaf(w, 0.24279078841f, 0.40000972152f);               // Lg4, Lg2
-    const float t2 = z * __builtin_fmaf(w, 0.28498786688f, 0.66666662693f);               // Lg3, Lg1
-    const float R = t2 + t1;
-    const float hfsq = 0.5f * f * f;
-    const float tail = __builtin_fmaf(dk, 9.0580006145e-06f, s * (hfsq + R));             // + k ln2_lo
-    return __builtin_fmaf(dk, 6.9313812256e-01f, -((hfsq - tail) - f));                    // k ln2_hi - ...
-}
-// expm1(x), x <= 0, with the TWO-step Cody-Waite reduction (ln2 = hi + lo, hi with 12 zero low bits so that k hi is exact):
-// the fast form's single fma leaves 2^k |k| 2^-26 of ln2's own rounding error in every result with k != 0 — always with the
-// same sign, so over 750 steps it adds up where rounding noise averages out
-constexpr float F32_LN2_HI = 0.693145751953125f;
-constexpr float F32_LN2_LO = 1.42860682030941723212e-6f;
-__device__ __forceinline__ float fe_expm1_neg_acc(float x) {
-    x = fmaxf(x, -87.0f);
-    const float u = __builtin_fmaf(x, F32_LOG2E, F32_RINT_MAGIC);
-    const float k = u - F32_RINT_MAGIC;
-    float r = __builtin_fmaf(-k, F32_LN2_HI, x);
-    r = __builtin_fmaf(-k, F32_LN2_LO, r);
-    const float p = fe_expm1_reduced(r);
-    const float s = fe_exp2_from_magic(u);
-    return __builtin_fmaf(s, p, s - 1.0f);
-}
-// which expm1 / reciprocal / logarithm gas_step() uses: the routines above by their lane type (every precision's default),
-// or the accurate fp32 forms
-struct MathDefault {
-    template <typename V> static __device__ __forceinline__ V expm1(const V x) { return fe_expm1_neg(x); }
-    template <typename V> static __device__ __forceinline__ V rcp(const V a) { return fe_rcp(a); }
-    template <typename V> static __device__ __forceinline__ V log(const V x) { return fe_log(x); }
-};
-struct MathAccurateF32 {
-    static __device__ __forceinline__ float expm1(const float x) { return fe_expm1_neg_acc(x); }
-    static __device__ __forceinline__ float rcp(const float a) { return fe_rcp_acc(a); }
-    static __device__ __forceinline__ float log(const float x) { return fe_log_acc(x); }
-};
-
 // ---------------------------------------------------------------------------------
 // One member, one step.  All state lives in registers; the caller moves it.
 //   drv : this step's drive record (LDS): [0..2] E_g, [3..5] cumE_g, [6] F_ext
@@ -415,7 +357,7 @@ struct MathAccurateF32 {
 // ---------------------------------------------------------------------------------
 // V is the lane value type (double, float, or float2v = two members per lane); S its scalar type: the shared model and
 // the drive record are S, everything per member is V.
-template <typename V, typename L, int g, bool INV, typename M = MathDefault>
+template <typename V, typename L, int g, bool INV>
 __device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, const KGas<typename Lane<V>::S>& kg,
                                       const typename Lane<V>::S* __restrict__ drv, const V (&rr)[3 * L::G], const V T_old,
                                       V (&R)[L::SP], V (&out)[L::G], V (&cum)[L::G]) {
@@ -437,11 +379,11 @@ __device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, con
     V iirf = fma3<V>(kg.ra, G_a, fma3<V>(rr[3 * g + 2], T_old, fma3<V>(rr[3 * g + 1], G_u, rr[3 * g])));
     iirf = fe_min(iirf, km.iirf_max);
     const V alpha = kg.g0 * fe_exp(iirf * kg.inv_g1);
-    const V inv_alpha = M::rcp(alpha);
+    const V inv_alpha = fe_rcp(alpha);
     // --- step_conc -----------------------------------------------------------------
     V em1[P];
 #pragma unroll
-    for (int i = 0; i < P; ++i) em1[i] = M::expm1(kg.ndt_over_tau[i] * inv_alpha);
+    for (int i = 0; i < P; ++i) em1[i] = fe_expm1_neg(kg.ndt_over_tau[i] * inv_alpha);
     V E;
     if constexpr (INV) {
         V num = V(0), den = V(0);
@@ -471,16 +413,16 @@ __device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, con
     const auto pos = fe_gt0(Cg);
     V Fg = kg.f2 * (Cg - kg.C0);
     if constexpr (Lane<V>::W == 1) {
-        if (kg.f1 != S(0)) Fg = pos ? fe_fma(kg.f1, M::log(pos ? Cg * kg.inv_C0 : S(1)), Fg) : Fg;
+        if (kg.f1 != S(0)) Fg = pos ? fe_fma(kg.f1, fe_log(pos ? Cg * kg.inv_C0 : S(1)), Fg) : Fg;
         if (kg.f3 != S(0)) Fg = fe_fma(kg.f3, (pos ? fe_sqrt(pos ? Cg : S(1)) : S(0)) - kg.sqrtC0, Fg);
     } else {
-        if (kg.f1 != S(0)) Fg = fe_sel(pos, fma3<V>(kg.f1, M::log(fe_sel(pos, Cg * kg.inv_C0, (V)S(1))), Fg), Fg);
+        if (kg.f1 != S(0)) Fg = fe_sel(pos, fma3<V>(kg.f1, fe_log(fe_sel(pos, Cg * kg.inv_C0, (V)S(1))), Fg), Fg);
         if (kg.f3 != S(0)) Fg = fma3<V>(kg.f3, fe_sel(pos, fe_sqrt(fe_sel(pos, Cg, (V)S(1))), (V)S(0)) - kg.sqrtC0, Fg);
     }
     return Fg;
 }
 
-template <typename V, typename L, bool INV = false, typename M = MathDefault>
+template <typename V, typename L, bool INV = false>
 __device__ __forceinline__ void member_step(const KModel<typename Lane<V>::S>& km, const typename Lane<V>::S* __restrict__ drv,
                                             const V (&rr)[3 * L::G], const V (&qq)[2],
                                             V (&R)[L::SP], V (&S)[2], V (&out)[L::G], V& Tnew, V (&cum)[L::G]) {
@@ -490,26 +432,26 @@ __device__ __forceinline__ void member_step(const KModel<typename Lane<V>::S>& k
     // ~45 being hoisted to the kernel top (VGPR pressure) or out of the fused time loop.  (Issuing gas
     // g+1's reads before gas g's arithmetic was tried: +-1 %, 133 VGPRs; not kept.)
     asm volatile("" ::: "memory");
-    F += gas_step<V, L, 0, INV, M>(km, km.gas[0], drv, rr, T_old, R, out, cum);
+    F += gas_step<V, L, 0, INV>(km, km.gas[0], drv, rr, T_old, R, out, cum);
     if constexpr (L::G > 1) {
         asm volatile("" ::: "memory");
-        F += gas_step<V, L, 1, INV, M>(km, km.gas[1], drv, rr, T_old, R, out, cum);
+        F += gas_step<V, L, 1, INV>(km, km.gas[1], drv, rr, T_old, R, out, cum);
     }
     if constexpr (L::G > 2) {
         asm volatile("" ::: "memory");
-        F += gas_step<V, L, 2, INV, M>(km, km.gas[2], drv, rr, T_old, R, out, cum);
+        F += gas_step<V, L, 2, INV>(km, km.gas[2], drv, rr, T_old, R, out, cum);
     }
     // --- step_temp: S + em1_d (S - q F) ------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 2; ++j) S[j] = fma3<V>(km.em1_d[j], fe_fma(-qq[j], F, S[j]), S[j]);
     Tnew = S[0] + S[1];
 }
-template <typename V, typename L, typename M = MathDefault>
+template <typename V, typename L>
 __device__ __forceinline__ void member_step(const KModel<typename Lane<V>::S>& km, const typename Lane<V>::S* __restrict__ drv,
                                             const V (&rr)[3 * L::G], const V (&qq)[2],
                                             V (&R)[L::SP], V (&S)[2], V (&C)[L::G], V& Tnew) {
     V unused[L::G];
-    member_step<V, L, false, M>(km, drv, rr, qq, R, S, C, Tnew, unused);
+    member_step<V, L, false>(km, drv, rr, qq, R, S, C, Tnew, unused);
 }
 
 // The shared model is the FIRST kernel argument (by value): its bytes sit at offset 0 of the
@@ -852,7 +794,7 @@ __device__ __forceinline__ unsigned int hist_bin2(const HistRule<float> r, const
 #else
 #define FIVEEQ_STEP_ATTR
 #endif
-template <typename V, int P0, int P1, int P2, bool BINS = false, typename M = MathDefault>
+template <typename V, int P0, int P1, int P2, bool BINS = false>
 __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kernel(
     const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps, const int t,
     const int64_t n, const int64_t ld,
@@ -901,7 +843,7 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
 
     V Tn = (V)T(0);
     {
-        member_step<V, L, M>(kmr, drv, rr, qq, Rv, Sv, Cv, Tn);
+        member_step<V, L>(kmr, drv, rr, qq, Rv, Sv, Cv, Tn);
         if (active) {
 #pragma unroll
         for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
@@ -953,7 +895,7 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
 // INV = true: concentration-driven form.  drive[t][0..2] are target concentrations, cumE [G][ld] is
 // per-member cumulative-emission state (in/out), and C_traj receives the DIAGNOSED EMISSIONS.
 // (112 VGPRs at fp64 4+1+1 = 4 waves/SIMD; launch-bounds hints for 5 or 6 waves spill: -3 % / -16 %.)
-template <typename V, int P0, int P1, int P2, bool INV, bool BINS = false, typename M = MathDefault>
+template <typename V, int P0, int P1, int P2, bool INV, bool BINS = false>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps,
     const int t_begin, const int t_end, const int64_t n, const int64_t ld,
@@ -1010,7 +952,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
         __syncthreads();
         for (int k = 0; k < nt; ++k) {
             const T* d = &drv[k * DRIVE_STRIDE];
-            member_step<V, L, INV, M>(kmr, d, rr, qq, Rv, Sv, Cv, Tn, cum);
+            member_step<V, L, INV>(kmr, d, rr, qq, Rv, Sv, Cv, Tn, cum);
             // the output row is wave-uniform: read it once into an SGPR so that the row test is a
             // scalar branch and the row offsets are scalar arithmetic, not 64-bit VALU per lane
             const int row = __builtin_amdgcn_readfirstlane((int)d[7]);
@@ -1031,11 +973,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
                         *o = (unsigned short)hist_bin(rule, Tn);
                     } else {
                         const unsigned int b01 = hist_bin2(rule, Tn);
-#ifdef FIVEEQ_RING_NT_STORE
-                        if (full) __builtin_nontemporal_store(b01, reinterpret_cast<unsigned int*>(o));
-#else
                         if (full) *reinterpret_cast<unsigned int*>(o) = b01;                // both members: one 4-byte store
-#endif
                         else *o = (unsigned short)(b01 & 0xffffu);
                     }
                 }
@@ -1407,16 +1345,6 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_rows_kernel(const int64_t n
 // Kernel 4b — the pass of the bin-index ring: hist[row][b] += #members whose stored bin index is b (BIN_NAN skipped).
 // Same grid shape and LDS privatisation as hist_rows_kernel; reads 2 bytes per member and row, four members per 8-byte load.
 // ---------------------------------------------------------------------------------
-// every byte of the ring is written once and read once
-__device__ __forceinline__ uint4 ring_load(const uint4* p) {
-#ifdef FIVEEQ_RING_NT_LOAD
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
-    return uint4{v.x, v.y, v.z, v.w};
-#else
-    return *p;
-#endif
-}
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_bins_kernel(const int64_t n, const int64_t ld, const int64_t chunk,
                                                                  const unsigned short* __restrict__ rows, const int n_bins,
                                                                  unsigned long long* __restrict__ hist) {
@@ -1471,12 +1399,12 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void hist_bins_kernel(const int64_t n
         const int64_t whole = m0 + (m1 - m0) / STRIDE * STRIDE;
         int64_t m8 = m0 + (int64_t)threadIdx.x * 8;
         for (; m8 + STRIDE < whole; m8 += 2 * STRIDE) {
-            const uint4 v = ring_load(reinterpret_cast<const uint4*>(x + m8));
-            const uint4 u = ring_load(reinterpret_cast<const uint4*>(x + m8 + STRIDE));
+            const uint4 v = *reinterpret_cast<const uint4*>(x + m8);
+            const uint4 u = *reinterpret_cast<const uint4*>(x + m8 + STRIDE);
             count8(v);
             count8(u);
         }
-        if (m8 < whole) count8(ring_load(reinterpret_cast<const uint4*>(x + m8)));
+        if (m8 < whole) count8(*reinterpret_cast<const uint4*>(x + m8));
         for (int64_t r = whole + threadIdx.x; r < m1; r += FIVEEQ_BLOCK) count(x[r]);
         m = m1;
     }
@@ -1871,12 +1799,6 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void math_probe_kernel(const int op, 
         }
     }
     if (i >= n) return;
-    if constexpr (sizeof(T) == 4) {
-        if (op >= 16) {                                      // the accurate fp32 forms (f32_math = 1): log, reciprocal
-            y[i] = op == 16 ? fe_expm1_neg_acc(x[i]) : (op == 18 ? fe_log_acc(x[i]) : fe_rcp_acc(x[i]));
-            return;
-        }
-    }
     y[i] = math_probe_eval(op, x[i]);
 }
 

@@ -78,8 +78,8 @@ class EnsembleEngine(CheckpointMixin):
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
                  device=None, store_trajectory=True, output_steps=None, store_concentrations=True,
                  collect_stats=False, hist=None, hist_ring_steps="auto", concentration_driven=False,
-                 chunk_members="auto", per_step_streams="auto", fused_span="auto", small_lanes="auto", fp32_math="fast",
-                 R0=None, S0=None, lib_path=None):
+                 chunk_members="auto", per_step_streams="auto", fused_span="auto", small_lanes="auto", R0=None,
+                 S0=None, lib_path=None):
         """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
         stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
         store_concentrations=False keeps only the T rows (a 100M-member fp32 run then stores 4 B instead
@@ -113,11 +113,7 @@ class EnsembleEngine(CheckpointMixin):
         "auto": FUSED_SPAN_STEPS when the ensemble is between FUSED_SPAN_MIN_ROUNDS and FUSED_SPAN_MAX_ROUNDS rounds of resident
         waves, else one launch (profiles/r03/relaunch_sweep.txt).  Bit-identical either way.
         small_lanes: mode='small' (single-gas layouts, no statistics / histograms): lanes per member, 4 (a lone 4-pool gas:
-        one pool per lane of a quad), 1, or "auto" = 4 while every quad wave gets a SIMD of its own, else 1.
-        fp32_math (dtype float32 only): "fast" — the reciprocal of alpha and the forcing's logarithm are the bare hardware
-        instructions, two members per lane: C within 2.9e-6, T within 1.7e-5 of 50-digit arithmetic over 750 steps — or
-        "accurate": a Newton step and an fdlibm-style logarithm, one member per lane (C 1.2e-6, T 1.1e-5; the fused kernel
-        takes ~1.3x as long; modes per_step / graph / fused / ksteps, no histograms)."""
+        one pool per lane of a quad), 1, or "auto" = 4 while every quad wave gets a SIMD of its own, else 1."""
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.lib = _capi.load(lib_path)    # raises if the HIP library is not built
@@ -137,8 +133,7 @@ class EnsembleEngine(CheckpointMixin):
         self.pools = pools_of(params)
         self.sum_pools = SP = sum(self.pools)
         self.dt = float(dt)
-        self.fp32_math = fp32_math
-        self.model = make_model(params, dt, f32_math=fp32_math)
+        self.model = make_model(params, dt)
         n_pools = (ctypes.c_int32 * G)(*self.pools)
         if not self.lib.fiveeq_layout_supported(G, n_pools):
             raise _capi.FiveEqError(_capi.E_UNSUPPORTED, f"pool layout {self.pools} has no compiled kernel")
@@ -260,8 +255,7 @@ class EnsembleEngine(CheckpointMixin):
     def small_form(self):
         """Lanes per member mode='small' would run with now (4 or 1); 0 = the small-ensemble kernel does not apply: several
         gases, or a run that wants per-wave statistics, in-loop histograms or the concentration-driven form."""
-        if (not self.small_widest or self.collect_stats or self.T_hist is not None or self.concentration_driven
-                or (self.fp32_math == "accurate" and self.dtype == torch.float32)):
+        if not self.small_widest or self.collect_stats or self.T_hist is not None or self.concentration_driven:
             return 0
         if self.small_lanes != "auto":
             return self.small_lanes if self.small_lanes in (1, self.small_widest) else 0

@@ -334,11 +334,8 @@ def sample_ensemble_shard(base, n_total, lo=0, hi=None, seed=LHS_SEED, device=No
 # ------------------------------------------------------------------------------------
 # pack the shared part into the C-ABI struct
 # ------------------------------------------------------------------------------------
-def make_model(params, dt=1.0, f32_math="fast"):
-    """Parameter dict -> ctypes `fiveeq_model` (include/fiveeq.h).  f32_math: "fast" | "accurate", the transcendental forms
-    of the fp32 entry points (the struct's f32_math field; fp64 ignores it)."""
-    if f32_math not in ("fast", "accurate"):
-        raise ValueError("f32_math must be 'fast' or 'accurate'")
+def make_model(params, dt=1.0):
+    """Parameter dict -> ctypes `fiveeq_model` (include/fiveeq.h)."""
     a = np.atleast_2d(np.asarray(params["a"], dtype=np.float64))
     tau = np.atleast_2d(np.asarray(params["tau"], dtype=np.float64))
     G = a.shape[0]
@@ -353,7 +350,6 @@ def make_model(params, dt=1.0, f32_math="fast"):
     d = np.asarray(params["d"], dtype=np.float64).reshape(_capi.N_BOX)
     m = _capi.Model()
     m.n_gas = G
-    m.f32_math = 1 if f32_math == "accurate" else 0
     m.dt = float(dt)
     m.iirf_max = float(params["iirf_max"])
     for j in range(_capi.N_BOX):

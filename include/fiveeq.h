@@ -79,23 +79,22 @@ typedef struct fiveeq_gas {
     int32_t reserved;
 } fiveeq_gas;
 
-/* Whole shared model.  Always given in double; the f32 entry points round it. */
+/* Whole shared model.  Always given in double; the f32 entry points round it.
+ * ACCURACY OF THE _f32 ENTRY POINTS, against 50-digit arithmetic over the 24 golden members x 750 steps
+ * (tests/test_golden_fiveeq.py): C within 2.9e-6 relative, T within 1.7e-5 (test bounds 5e-6 / 3e-5 + 2e-6 K).  What bounds
+ * it is the fp32 rounding of the STATE carried through 750 steps (~13 ulp of C at the end), not the transcendental forms:
+ * with a two-step expm1 reduction, a Newton step on the reciprocal and an fdlibm-style logarithm in place of the hardware
+ * v_rcp_f32 / v_log_f32 forms the same members changed 48 of 840 stored values and no worst case, for +21 % on the
+ * time-fused kernel (profiles/r05/fp32_math_ab.txt; the variant was measured at commit 51b82a6 and not kept).  A run that
+ * needs more digits than that runs the _f64 entry points. */
 typedef struct fiveeq_model {
     fiveeq_gas gas[FIVEEQ_MAX_GAS];
     double  d[FIVEEQ_N_BOX];        /* thermal-box time-scales, years       */
     double  iirf_max;               /* clip on iIRF (e.g. 97)               */
     double  dt;                     /* step length, years                   */
     int32_t n_gas;                  /* 1..3                                  */
-    int32_t f32_math;               /* the _f32 entry points only: 0 = fast, 1 = accurate (below); _f64 ignores it */
+    int32_t reserved;
 } fiveeq_model;
-/* f32_math.  fp32 results against 50-digit arithmetic over the 24 golden members, 750 steps (tests/test_golden_fiveeq.py):
- *   0 (fast, the default)  C within 2.9e-6 relative, T within 1.7e-5: the reciprocal of alpha and the forcing's logarithm are
- *                          the bare hardware instructions (v_rcp_f32, v_log_f32), two members per lane where the rows allow;
- *   1 (accurate)           C within 1.2e-6, T within 1.1e-5: a Newton step on the reciprocal and an fdlibm-style logarithm
- *                          (< 1 ulp), one member per lane — the time-fused kernel takes ~1.3x as long.  Served by step / run /
- *                          run_fused / run_ksteps / plan_create _f32; the streamed-histogram, concentration-driven and
- *                          small-ensemble entry points return FIVEEQ_E_UNSUPPORTED for it.
- * What remains in both is fp32 rounding of the state itself over 750 steps. */
 
 /* Array shapes used below (G = n_gas, SP = sum of n_pools over gases):
  *   drive   dev [n_steps][8]   shared by all members, per step:
@@ -379,7 +378,7 @@ int fiveeq_stream_copy_wide_f64(int64_t n, const double *src, double *dst, void 
  * pin each against a CPU libm to the ulp.  op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0, finite normal),
  * 3 sqrt (x > 0, finite normal), 4 reciprocal (x > 0, finite normal).  _f32 only: op + 8 evaluates the PACKED twin of
  * the primitive (two members per lane, fiveeq_set_f32_packing above) on the element pairs (x[2i], x[2i+1]), n even:
- * it must return the scalar routine's bits; op 16 / 18 / 20 = the ACCURATE expm1 / log / reciprocal (f32_math = 1). */
+ * it must return the scalar routine's bits. */
 int fiveeq_math_probe_f64(int32_t op, int64_t n, const double *x, double *y, void *stream);
 int fiveeq_math_probe_f32(int32_t op, int64_t n, const float *x, float *y, void *stream);
 

@@ -207,15 +207,6 @@ def test_new_entry_points_validate_on_the_host():
     for n_lanes in (0, 1, 4):
         assert small(co2, n_lanes, 2, 2) == _capi.OK                   # empty span: nothing to launch
     assert lib.fiveeq_run_small_f32(ctypes.byref(co2), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, 0, None) == _capi.OK
-    acc = prm.make_model(prm.default_params("co2"), f32_math="accurate")               # the accurate fp32 forms: no small form
-    assert lib.fiveeq_run_small_f32(ctypes.byref(acc), 8, 8, p, 4, 0, 4, p, p, p, p, None, None, 0, 0, None) == _capi.E_UNSUPPORTED
-    assert b"accurate" in lib.fiveeq_last_error()
-    assert lib.fiveeq_run_small_f64(ctypes.byref(acc), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, 0, None) == _capi.OK   # fp64 ignores it
-    acc.f32_math = 7
-    assert lib.fiveeq_run_f32(ctypes.byref(acc), 8, 8, p, 4, 0, 4, p, p, p, p, None, None, 0, None, None) == _capi.E_INVALID
-    assert b"f32_math" in lib.fiveeq_last_error()
-    with pytest.raises(ValueError, match="f32_math"):
-        prm.make_model(prm.default_params("co2"), f32_math="exact")
     one_pool = dict(prm.default_params("co2"))
     bad = lib.fiveeq_run_small_f64(ctypes.byref(co2), 8, 8, None, 4, 0, 4, p, p, p, p, None, None, 0, 0, None)
     assert bad == _capi.E_INVALID and b"NULL" in lib.fiveeq_last_error() and one_pool

@@ -145,13 +145,6 @@ def test_device_math_primitives_fp32(gpu):
     assert ulp32(got, np.sqrt(xx)).max() <= 1.0
     got, xx = probe(4, x)
     assert ulp32(got, 1.0 / xx).max() <= 1.0
-    # the ACCURATE forms (fiveeq_model.f32_math = 1): fdlibm-style logarithm < 1 ulp (also next to 1), Newton reciprocal <= 0.51
-    got, xx = probe(18, x)
-    u = ulp32(got[nz], np.log(xx)[nz])
-    assert u.max() <= 1.0 and u.mean() < 0.4, (u.max(), u.mean())
-    assert probe(18, np.array([1.0, 1.0]))[0].tolist() == [0.0, 0.0]
-    got, xx = probe(20, x)
-    assert ulp32(got, 1.0 / xx).max() <= 0.51
 
 
 # ---- the reference's function, ensemble form ---------------------------------------------------

@@ -293,48 +293,33 @@ def test_kernels_reproduce_the_extra_golden_cases(golden):
 @pytest.mark.gpu
 def test_fp32_kernels_against_50_digit_arithmetic(capsys):
     """BASELINE configs[4] runs in fp32: its error budget against the EXACT discrete model (50-digit reference), not
-    only against the fp64 kernels, over all 750 steps for ALL 24 golden members — for BOTH fp32 math settings
-    (include/fiveeq.h, f32_math): "fast" (the default: hardware reciprocal and logarithm) C within 5e-6 relative, T within
-    3e-5 relative + 2e-6 K; "accurate" (Newton step, fdlibm-style logarithm) C within 2e-6, T within 2e-5 + 2e-6 K — the
-    digits round 3 traded for speed, available again.  (The increment form x + expm1(.)(x - x_eq) is what keeps the
-    tau = 1e6 yr pool alive in fp32.)"""
+    only against the fp64 kernels: C within 5e-6 relative, T within 3e-5 relative + 2e-6 K over all 750 steps for ALL 24
+    golden members (measured: C 2.9e-6, T 1.7e-5 — include/fiveeq.h states these).  What bounds it is the fp32 rounding of the
+    STATE over 750 steps, not the transcendental forms: round 5 ran the same members with a two-step expm1 reduction, a
+    Newton step on the reciprocal and an fdlibm-style logarithm instead of the hardware forms — 48 of 840 stored values
+    changed, the worst case not at all (profiles/r05/fp32_math_ab.txt).  (The increment form x + expm1(.)(x - x_eq) is what
+    keeps the tau = 1e6 yr pool alive in fp32.)"""
     torch = pytest.importorskip("torch")
     from fiveeqscm_amd.engine import EnsembleEngine
     ref = _load("fiveeq_mp_reference.json")
-    bounds = {"fast": (5e-6, 3e-5), "accurate": (2e-6, 2e-5)}
     worst = {}
-    for math in ("fast", "accurate"):
-        for kind in ("co2", "multigas"):
-            p, N = cases.members(kind)
-            for mode in ("per_step", "fused", "ksteps"):
-                eng = EnsembleEngine(p, N, cases.scenario(kind), dtype=torch.float32, device="cuda:0", output_steps=cases.STEPS,
-                                     fp32_math=math)
-                eng.run(mode=mode, k_steps=7 if mode == "ksteps" else None)
-                torch.cuda.synchronize()
-                C, T = eng.C.double().cpu().numpy(), eng.T.double().cpu().numpy()
-                if mode == "per_step":
-                    first = (eng.C.clone(), eng.T.clone())
-                else:                                                     # every launch shape gives the setting's bits
-                    assert torch.equal(eng.C, first[0]) and torch.equal(eng.T, first[1]), (math, kind, mode)
-                for i, m in enumerate(ref["members"]):
-                    C_mp = np.array([[float(v) for v in row] for row in ref["cases"][kind]["C"][i]])
-                    T_mp = np.array([float(v) for v in ref["cases"][kind]["T"][i]])
-                    eC = np.abs(C[:, :, m] - C_mp) / np.abs(C_mp)
-                    eT = np.abs(T[:, m] - T_mp) / (np.abs(T_mp) + 1e-2)
-                    w = worst.get((math, kind), (0.0, 0.0, 0.0))
-                    worst[(math, kind)] = (max(w[0], float(eC.max())), max(w[1], float(eT.max())),
-                                           max(w[2], float((np.abs(T[:, m] - T_mp) / (bounds[math][1] * np.abs(T_mp) + 2e-6)).max())))
-                eng.close()
+    for kind in ("co2", "multigas"):
+        p, N = cases.members(kind)
+        for mode in ("per_step", "fused"):
+            eng = EnsembleEngine(p, N, cases.scenario(kind), dtype=torch.float32, device="cuda:0", output_steps=cases.STEPS)
+            eng.run(mode=mode)
+            torch.cuda.synchronize()
+            C, T = eng.C.double().cpu().numpy(), eng.T.double().cpu().numpy()
+            for i, m in enumerate(ref["members"]):
+                C_mp = np.array([[float(v) for v in row] for row in ref["cases"][kind]["C"][i]])
+                T_mp = np.array([float(v) for v in ref["cases"][kind]["T"][i]])
+                eC = np.abs(C[:, :, m] - C_mp) / np.abs(C_mp)
+                eT = np.abs(T[:, m] - T_mp) / (np.abs(T_mp) + 1e-2)
+                w = worst.get(kind, (0.0, 0.0, 0.0))
+                worst[kind] = (max(w[0], float(eC.max())), max(w[1], float(eT.max())),
+                               max(w[2], float((np.abs(T[:, m] - T_mp) / (3e-5 * np.abs(T_mp) + 2e-6)).max())))
     with capsys.disabled():
         print(f"\n  fp32 kernels vs 50-digit arithmetic over {len(ref['members'])} members, worst (relative error of C, "
               f"relative error of T with a 1e-2 K floor, T error / its bound): {worst}")
-    for (math, kind), (eC, _, eT_bound) in worst.items():
-        assert eC <= bounds[math][0] and eT_bound <= 1.0, (math, kind, worst[(math, kind)])
-    assert all(worst[("accurate", k)][0] < worst[("fast", k)][0] for k in ("co2", "multigas"))
-    # the accurate setting is served by the per-step / fused families only
-    p, N = cases.members("co2")
-    eng = EnsembleEngine(p, N, cases.scenario("co2"), dtype=torch.float32, device="cuda:0", fp32_math="accurate", hist=(-1.0, 5.0, 64))
-    from fiveeqscm_amd import _capi
-    with pytest.raises(_capi.FiveEqError, match="accurate"):
-        eng.run(mode="fused")
-    assert EnsembleEngine(p, N, cases.scenario("co2"), dtype=torch.float32, device="cuda:0", fp32_math="accurate").small_form() == 0
+    for kind, (eC, _, eT_bound) in worst.items():
+        assert eC <= 5e-6 and eT_bound <= 1.0, (kind, worst[kind])
