@@ -57,6 +57,19 @@ python3 $R/tools/pmc_valu.py $OUT/sq_counters_lds_f32_4M.csv $OUT/lds_valu_scrat
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_fused -- python3 $R/tools/pmc_workload_fused_traffic.py > $OUT/pmc_fetch_fused.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_fused -- python3 $R/tools/pmc_workload_fused_traffic.py > $OUT/pmc_write_fused.log 2>&1
 python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_fused $OUT/pmc_write_fused 134217728 fused:f64:1000000 $OUT/traffic.json fused > /dev/null
+# keep what is judged, drop the raw per-dispatch tables: gpurun brings back at most 64 MiB
+for n in fetch_1000000 write_1000000 fetch_8000000 write_8000000 fetch_fused write_fused; do
+  src=$(ls -t $OUT/pmc_$n/*/*counter_collection.csv 2>/dev/null | head -1)
+  case $n in fetch_fused) dst=pmc_fetch_fused_1000000;; write_fused) dst=pmc_write_fused_1000000;; *) dst=pmc_$n;; esac
+  [ -n "$src" ] && head -40 "$src" > $OUT/$dst.head.csv
+done
+for pair in trace:bench_config3 trace_config2:bench_config2_auto trace_config5_demo:config5_demo_streamed_pipeline; do
+  t=${pair%%:*}; name=${pair##*:}
+  for k in kernel_stats domain_stats; do
+    src=$(ls -t $OUT/$t/*/*_$k.csv 2>/dev/null | head -1); [ -n "$src" ] && cp "$src" $OUT/${k}_$name.csv
+  done
+done
+for d in $OUT/pmc_* $OUT/trace $OUT/trace_config2 $OUT/trace_config5_demo; do [ -d "$d" ] && rm -rf "$d"; done
 fi
 if [ "$QUICK" != "quick" ]; then
 if [ "$QUICK" != "sweeps" ]; then          # (sweeps = the tables only: tools/collect_final_bench_lines.sh regenerates every bench line)
