@@ -19,7 +19,8 @@ STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 96
 kind = sys.argv[4] if len(sys.argv) > 4 else "multigas"
 small = len(sys.argv) > 5 and sys.argv[5] == "small"
 p = params.sample_ensemble_shard(params.default_params(kind), N, device="cuda:0", dtype=dt)
-E = emissions.rcp_like_emissions(750, 3 if kind == "multigas" else 1)[250:250 + STEPS]
+E = emissions.rcp_like_emissions(max(750, 250 + STEPS), 3 if kind == "multigas" else 1)[250:250 + STEPS]
+assert E.shape[0] == STEPS
 if small:
     for lanes in (4, 1):
         eng = EnsembleEngine(p, N, E, dtype=dt, device="cuda:0", small_lanes=lanes)       # trajectories stored, like config 2
