@@ -29,8 +29,10 @@ kernel as ONE launch per timestep on one stream (north_star's literal shape) bes
 (NumPy, one process per usable core, and the plain-C port under OpenMP) on this box's host cores on a bounded sample
 (rank 0, N=1 only) BEFORE the GPU is touched, so that the GPU work of the run is one contiguous window.
 
-With N > 1 and no explicit --mode the per-step form falls back to its hipGraph replay (same kernels, same bits) when the slowest
-rank's host thread needs more than --host-share-limit (0.5) of a step to enqueue it: `config.mode`, `timing.host_fallback`.
+The default launch form is the per-step one at EVERY N, so that the driver's N = 1, 2, 4, 8 values compare like with like.  With
+N > 1 the line also says whether the slowest rank's host thread needs more than --host-share-limit (0.5) of a step to enqueue it
+(`timing.host_fallback.would_switch`); only with --host-fallback does the timed region then switch to the hipGraph replay of the
+same launches (same kernels, same bits): `config.mode` says what ran.
 
 N > 1: one process per GPU; time-stepping needs no collective.  The line proves what ran: `config.devices` (every rank's device
 index, name, PCI bus id, uuid), `timing.per_rank_ms_per_step`, `timing.per_rank_host_enqueue_us` — gathered over the control
@@ -157,9 +159,11 @@ def parse():
     ap.add_argument("--members", type=int, default=0, help="members per GPU (default: the workload's)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default=None, choices=["per_step", "graph", "fused", "ksteps", "small", "auto"],
-                    help="default: per_step — and, for N > 1 only, its hipGraph replay (same kernels, same bits) if the host "
-                         "thread of the slowest rank needs more than --host-share-limit of a step to enqueue it")
+                    help="default: per_step at every N (see --host-fallback)")
     ap.add_argument("--host-share-limit", type=float, default=0.5)
+    ap.add_argument("--host-fallback", action="store_true",
+                    help="N > 1 without --mode: switch the timed region to graph replay when the per-step enqueue share reaches "
+                         "--host-share-limit (default: measure and report it, keep the per-step form)")
     ap.add_argument("--k-steps", type=int, default=0, help="steps per launch for --mode ksteps (0: the engine's choice)")
     ap.add_argument("--no-trajectory", action="store_true", help="do not store C/T rows (drops G+1 writes from A)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -521,10 +525,11 @@ def main():
         med, mn, dmed = max_over_ranks([float(np.median(enq)), float(np.min(enq)), float(np.median(dev_t))])
         return med, mn, dmed, t_from
 
-    # Which launch form the timed region uses.  An explicit --mode is taken as given.  The default is the per-step form —
-    # and, for N > 1 only, its hipGraph replay when the slowest rank's host thread needs more than --host-share-limit of a
-    # step to enqueue it with all ranks enqueuing at once (same kernels in the same layout, bit-identical results; 1/4 of the
-    # host time): a host-bound node must not pass for a slow GPU.  `config.mode` says what ran, `timing.host_*` why.
+    # Which launch form the timed region uses.  An explicit --mode is taken as given.  The default is the per-step form at
+    # every N (the scaling curve must compare one launch form with itself).  For N > 1 the per-step enqueue share is measured
+    # first with all ranks enqueuing at once and reported (`timing.host_fallback`: a host-bound node must not pass for a slow
+    # GPU); with --host-fallback a share at or above --host-share-limit switches the timed region to the hipGraph replay of the
+    # same launches (same kernels in the same layout, bit-identical results; 1/4 of the host time).  `config.mode` says what ran.
     mode_requested = a.mode
     fallback = None
     if a.mode is None:
@@ -532,8 +537,10 @@ def main():
         if world > 1 or os.environ.get("FIVEEQ_BENCH_FORCE_HOST_CHECK") == "1":
             e_med, _, d_med, t_idx = host_enqueue("per_step", t_idx)
             fallback = {"per_step_host_enqueue_us_per_step": e_med * 1e6, "per_step_burst_us_per_step": d_med * 1e6,
-                        "per_step_host_share": e_med / d_med, "limit": a.host_share_limit, "switched_to_graph": False}
-            if e_med / d_med >= a.host_share_limit:
+                        "per_step_host_share": e_med / d_med, "limit": a.host_share_limit,
+                        "would_switch": bool(e_med / d_med >= a.host_share_limit), "enabled": bool(a.host_fallback),
+                        "switched_to_graph": False}
+            if fallback["would_switch"] and a.host_fallback:
                 a.mode, fallback["switched_to_graph"] = "graph", True
 
     def timed_block(t_from):
@@ -634,13 +641,14 @@ def main():
                           "concurrent launches); MAX over ranks per block, then the median block")}
     # ---- the rows the end-of-run exchange will summarise: taken NOW, from ONE uninterrupted run (the repeated blocks
     # cycled through the scenario and overwrote stored rows with later passes; the roofline batches below overwrite more) ---
+    # The WHOLE 750-step scenario, whatever K: the exchange then summarises the years 2014 / 2264 / 2514 of the run, not a
+    # near-constant row 24 steps in (26 ms of device time at 1M members, outside every clocked region).
     rows, years = None, []
     if eng.T is not None:
         eng.reset_state()
-        run_steps(eng, 0, min(a.warmup + a.steps, n_scen), a.mode, k_steps)
+        run_steps(eng, 0, n_scen, a.mode, k_steps)
         torch.cuda.synchronize(dev)
-        done_steps = min(a.warmup + a.steps, n_scen)            # scenario steps of that run
-        years = [t for t in (249, 499, 749) if t < done_steps] or [done_steps - 1]
+        years = [249, 499, 749]
         rows = eng.T[years]                                     # advanced indexing: a copy
 
     # ---- roofline: per-launch duration of the timed mode's kernel, HIP events on the launch stream ----

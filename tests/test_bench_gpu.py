@@ -135,7 +135,7 @@ def test_multi_rank_launch_prints_one_line_and_the_world_size_invariant_summary(
     assert abs(d["value"] - n * 200000 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     lo_ms, med_ms, hi_ms = d["timing"]["block_ms_min_median_max"]
     assert lo_ms <= med_ms <= hi_ms and abs(med_ms - d["ms_per_step"] * 20) < 1e-9 * med_ms
-    assert d["summary"]["bytes_to_root"] > 0 and d["summary"]["years"] == [24]
+    assert d["summary"]["bytes_to_root"] > 0 and d["summary"]["years"] == [249, 499, 749]
     # the line proves what ran: n distinct ranks, their devices, their own timings, and the exchange group as it reports itself
     devs = d["config"]["devices"]
     assert [x["rank"] for x in devs] == list(range(n)) and len({x["pid"] for x in devs}) == n
@@ -152,7 +152,7 @@ def test_multi_rank_launch_prints_one_line_and_the_world_size_invariant_summary(
     # the sharding, the kernels and the exchange.
     one = _bench("--steps", "20", "--warmup", "5", "--members", str(n * 200000), "--no-cpu-baseline", "--no-hbm-resident",
                  "--kernel-batches", "1")
-    assert one["n_gpus"] == 1 and one["summary"]["years"] == [24]
+    assert one["n_gpus"] == 1 and one["summary"]["years"] == [249, 499, 749]
     _summaries_agree(d["summary"], one["summary"])
     # ... and the PLAIN form, `python3 bench.py --gpus n` with no launcher (how the driver calls --gpus 1): bench.py starts
     # the ranks itself and the one line that comes back carries the same summary
@@ -208,23 +208,25 @@ def test_an_rccl_failure_on_first_contact_costs_the_summary_not_the_measurement(
 
 
 def test_a_host_bound_multi_rank_run_falls_back_to_graph_replay():
-    """N > 1, no explicit --mode: if the slowest rank's host thread needs more than --host-share-limit of a step to enqueue
-    it, the timed region runs the hipGraph replay of the same launches (same kernels, same bits).  Forced here with a limit
-    of 0 and excluded with a limit of 100; the default limit decides by this box's measured share; an explicit --mode is
-    never overridden."""
-    forced = _one_line(_plain(2, *_SMALL, "--host-share-limit", "0"))
+    """N > 1, no explicit --mode: the line reports whether the slowest rank's host thread needs more than --host-share-limit of a
+    step to enqueue it (`would_switch`); the default keeps the per-step form at every N (the scaling curve compares one launch
+    form with itself), and only --host-fallback switches the timed region to the hipGraph replay of the same launches (same
+    kernels, same bits).  Forced here with a limit of 0 and excluded with a limit of 100; an explicit --mode is never overridden."""
+    reported = _one_line(_plain(2, *_SMALL, "--host-share-limit", "0"))
+    fb = reported["timing"]["host_fallback"]
+    assert reported["config"]["mode"] == "per_step" and fb["would_switch"] is True and fb["enabled"] is False and fb["switched_to_graph"] is False
+    forced = _one_line(_plain(2, *_SMALL, "--host-share-limit", "0", "--host-fallback"))
     assert forced["config"]["mode"] == "graph" and forced["config"]["mode_requested"] == "default"
     fb = forced["timing"]["host_fallback"]
-    assert fb["switched_to_graph"] is True and fb["per_step_host_share"] > 0 and fb["limit"] == 0.0
-    kept = _one_line(_plain(2, *_SMALL, "--host-share-limit", "100"))               # a limit no box reaches: never switches
+    assert fb["switched_to_graph"] is True and fb["per_step_host_share"] > 0 and fb["limit"] == 0.0 and fb["enabled"] is True
+    kept = _one_line(_plain(2, *_SMALL, "--host-share-limit", "100", "--host-fallback"))     # a limit no box reaches: never switches
     assert kept["config"]["mode"] == "per_step" and kept["timing"]["host_fallback"]["switched_to_graph"] is False
-    default = _one_line(_plain(2, *_SMALL))                                          # the default limit: whatever this box's share says
+    default = _one_line(_plain(2, *_SMALL))                                          # the default: reported, not acted on
     fb_d = default["timing"]["host_fallback"]
-    assert fb_d["limit"] == 0.5 and fb_d["switched_to_graph"] == (fb_d["per_step_host_share"] >= 0.5)
-    assert default["config"]["mode"] == ("graph" if fb_d["switched_to_graph"] else "per_step")
+    assert fb_d["limit"] == 0.5 and fb_d["would_switch"] == (fb_d["per_step_host_share"] >= 0.5) and default["config"]["mode"] == "per_step"
     _summaries_agree(forced["summary"], kept["summary"], rel=0.0)                  # bit-identical kernels
     assert forced["timing"]["host_enqueue_us_per_step"] < kept["timing"]["host_enqueue_us_per_step"]
-    explicit = _one_line(_plain(2, *_SMALL, "--mode", "per_step", "--host-share-limit", "0"))
+    explicit = _one_line(_plain(2, *_SMALL, "--mode", "per_step", "--host-share-limit", "0", "--host-fallback"))
     assert explicit["config"]["mode"] == "per_step" and explicit["timing"]["host_fallback"] is None
     one = _bench(*_SMALL)
     assert one["config"]["mode"] == "per_step" and one["config"]["mode_requested"] == "default" and one["timing"]["host_fallback"] is None

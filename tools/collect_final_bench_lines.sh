@@ -15,6 +15,8 @@ for S in a b c; do eval C=\$SQ$(echo $S | tr a-z A-Z); timeout -k 10 300 rocprof
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_f32_4M.csv $OUT/valu.json 96 $OUT/pmc_sqa_fused32 $OUT/pmc_sqb_fused32 $OUT/pmc_sqc_fused32 > /dev/null
 for S in a c; do eval C=\$SQ$(echo $S | tr a-z A-Z); timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_sq${S}_step32 -- python3 $R/tools/pmc_workload.py 4000000 multigas f32 > $OUT/pmc_sq${S}_step32.log 2>&1; echo "step32 $S"; done
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_step_f32_4M.csv $OUT/valu.json 1 $OUT/pmc_sqa_step32 $OUT/pmc_sqc_step32 > /dev/null
+for S in a b; do eval C=\$SQ$(echo $S | tr a-z A-Z); timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_sq${S}_small -- python3 $R/tools/pmc_workload_fused.py 10000 f64 750 co2 small > $OUT/pmc_sq${S}_small.log 2>&1; echo "small $S"; done
+python3 $R/tools/pmc_valu.py $OUT/sq_counters_small_co2_f64_10k.csv $OUT/valu.json 750 $OUT/pmc_sqa_small $OUT/pmc_sqb_small > /dev/null
 cp $OUT/valu.json $R/profiles/valu.json
 cd $R
 python3 bench.py > $OUT/bench_config3.json 2> $OUT/bench_config3.err; echo bench1
@@ -34,5 +36,5 @@ python3 bench.py --no-cpu-baseline --workload config5 --dtype f32 --mode fused -
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-hbm-resident > $OUT/bench_config3_under_rocprof.json 2> $OUT/trace.err
 for k in kernel_stats domain_stats; do src=$(ls -t $OUT/trace/*/*_$k.csv 2>/dev/null | head -1); [ -n "$src" ] && cp "$src" $OUT/${k}_bench_config3.csv; done
-rm -rf $OUT/pmc_sq*_fused32 $OUT/pmc_sq*_step32 $OUT/trace
+rm -rf $OUT/pmc_sq*_fused32 $OUT/pmc_sq*_step32 $OUT/pmc_sq*_small $OUT/trace
 ls $OUT
