@@ -742,7 +742,9 @@ def main():
         if mode_run == "small":
             lpm = eng.small_form()
             span, kname, mode_t = n_scen, "small_kernel", "small"
-            lname, vtag, members_per_wave = f"{tname},{eng.pools[0]},{lpm}", a.dtype, 64 // lpm      # (never packed)
+            single = len(eng.pools) == 1
+            lname = f"{tname},{eng.pools[0]},{lpm}" if single else f"{tname},{pools3}"
+            vtag, members_per_wave = a.dtype, 64 // lpm                  # (never packed)
         elif mode_run == "fused":
             span, kname, mode_t = eng.fused_span_steps(n_scen), "fused_kernel", "fused"     # the engine relaunches small ensembles
         else:
@@ -764,7 +766,8 @@ def main():
         reps = -(-n_scen // span)
         k_avg = float(samples.mean())                           # seconds per model step inside the kernel
         achieved = A * n_local / k_avg / 1e9
-        kernel_name = (f"fiveeq::small_kernel<{lname}>" if kname == "small_kernel" else f"fiveeq::{kname}<{lname},{pools3}>")
+        kernel_name = ((f"fiveeq::small_kernel<{lname}>" if single else f"fiveeq::small_multi_kernel<{lname}>")
+                       if kname == "small_kernel" else f"fiveeq::{kname}<{lname},{pools3}>")
         roofline = {"bound": "fp64-valu" if a.dtype == "f64" else "fp32-valu", "unit": "wave-instr/s",
                     "achieved": None, "peak": valu_peak, "frac": None, "traffic": None,
                     "kernel": kernel_name, "steps_per_launch": span,

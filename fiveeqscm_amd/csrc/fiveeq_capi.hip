@@ -341,16 +341,10 @@ int run_ksteps(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int
     return FIVEEQ_OK;
 }
 
-// ---- small ensembles: one member per quad of lanes (small_kernel) ------------------------------------
-// lanes per member of the widest small-ensemble form compiled for a layout: 4 for a lone 4-pool gas, 1 for any other
-// single-gas layout, 0 = none (several gases)
-int small_lanes(int code) {
-    switch (code) {
-        case 400: return 4;
-        case 100: case 200: case 300: return 1;
-        default: return 0;
-    }
-}
+// ---- small ensembles: one member per quad of lanes (small_kernel), several gases one per lane (small_multi_kernel) -----
+// lanes per member of the widest small-ensemble form compiled for a layout: 4 for a lone 4-pool gas, 1 for every other
+// compiled layout, 0 = none
+int small_lanes(int code) { return code == 400 ? 4 : (layout_ok(code) ? 1 : 0); }
 
 template <typename T>
 int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
@@ -359,7 +353,6 @@ int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     RunArgs<T> a;
     if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, nullptr)) return rc;
     const int widest = small_lanes(a.code);
-    if (widest == 0) return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no small-ensemble kernel", a.code);
     if (lanes == 0) lanes = widest;
     if (lanes != 1 && lanes != widest)
         return fail(FIVEEQ_E_INVALID, "lanes_per_member=%d: pool layout %03d takes 1%s", lanes, a.code, widest == 4 ? " or 4" : "");
@@ -369,18 +362,22 @@ int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_SMALL_BLOCK);
     hipStream_t st = (hipStream_t)stream;
-#define FIVEEQ_SMALL(p0, lpm)                                                                                       \
-    hipLaunchKernelGGL((small_kernel<T, p0, lpm>), grid, block, 0, st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, \
-                       a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows)
+#define FIVEEQ_SMALL_ARGS st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows
     switch (a.code * 10 + lanes) {
-        case 1001: FIVEEQ_SMALL(1, 1); break;
-        case 2001: FIVEEQ_SMALL(2, 1); break;
-        case 3001: FIVEEQ_SMALL(3, 1); break;
-        case 4001: FIVEEQ_SMALL(4, 1); break;
-        case 4004: FIVEEQ_SMALL(4, 4); break;
-        default: return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no small-ensemble kernel", a.code);
+        case 1001: hipLaunchKernelGGL((small_kernel<T, 1, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
+        case 2001: hipLaunchKernelGGL((small_kernel<T, 2, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
+        case 3001: hipLaunchKernelGGL((small_kernel<T, 3, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
+        case 4001: hipLaunchKernelGGL((small_kernel<T, 4, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
+        case 4004: hipLaunchKernelGGL((small_kernel<T, 4, 4>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
+#define X(p0, p1, p2)                                                                                              \
+    case ((p0) * 100 + (p1) * 10 + (p2)) * 10 + 1:                                                                 \
+        if constexpr ((p1) > 0) hipLaunchKernelGGL((small_multi_kernel<T, p0, p1, p2>), grid, block, 0, FIVEEQ_SMALL_ARGS); \
+        break;
+        X(1, 1, 0) X(4, 1, 0) X(4, 4, 0) X(1, 1, 1) X(4, 1, 1) X(4, 4, 1) X(4, 4, 4)
+#undef X
+        default: return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
     }
-#undef FIVEEQ_SMALL
+#undef FIVEEQ_SMALL_ARGS
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;
 }

@@ -1176,6 +1176,89 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
     }
 }
 
+// The same for layouts with SEVERAL gases, one member per lane: member_step() itself on a model that lives in registers
+// (scalar loads of the kernel argument, hoisted out of the time loop: with at most two waves per SIMD the ~45 constants of
+// three gases fit beside the state) and on a drive record held in registers and read one step ahead.  What a launch-bound
+// multi-gas ensemble gains over the fused kernel is the LDS round trips per step that nothing hides when a wave is alone on
+// its SIMD.  (A quad per gas would carry 4 members per wave: worth it below ~4k members only; not built.)
+template <typename T, int P0, int P1, int P2>
+__global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void small_multi_kernel(
+    const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
+    const int64_t n, const int64_t ld, const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R,
+    T* __restrict__ S, T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
+    const int n_rows) {
+    using L = Layout<P0, P1, P2>;
+    __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
+    __shared__ int row_s[FIVEEQ_FUSED_CHUNK];
+    // fp64: the model, word by word, into VECTOR registers.  Left to itself the compiler keeps the ~45 constants of three
+    // gases in scalar registers, runs out of them (two each) and spills — 83 v_readlane per step, 1.25 us per step instead of
+    // 0.94 at 10k members (r05/ab_variants.txt section 4).  fp32 constants fit the scalar file and stay there (0.51 against 0.61).
+    KModel<T> kl;
+    {
+        constexpr int NW = sizeof(KModel<T>) / sizeof(T);
+        const T* src = reinterpret_cast<const T*>(&km);
+        T* dst = reinterpret_cast<T*>(&kl);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            T v = src[i];
+            if constexpr (sizeof(T) == 8) asm("" : "+v"(v));             // (not volatile: words of absent gases are dropped)
+            dst[i] = v;
+        }
+    }
+    const int64_t m = (int64_t)blockIdx.x * FIVEEQ_SMALL_BLOCK + threadIdx.x;
+    const bool active = m < n;
+    const int64_t mm = active ? m : 0;
+    T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
+#pragma unroll
+    for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 3 * L::G; ++k) rr[k] = r[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
+    for (int tc = t_begin; tc < t_end; tc += FIVEEQ_FUSED_CHUNK) {
+        const int nt = min(FIVEEQ_FUSED_CHUNK, t_end - tc);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += FIVEEQ_SMALL_BLOCK) {
+            const T v = drive[(int64_t)tc * DRIVE_STRIDE + i];
+            drv[i] = v;
+            if ((i & (DRIVE_STRIDE - 1)) == 7) row_s[i >> 3] = (int)v;
+        }
+        __syncthreads();
+        T cur[DRIVE_STRIDE - 1];
+#pragma unroll
+        for (int j = 0; j < DRIVE_STRIDE - 1; ++j) cur[j] = drv[j];
+        int rowv = row_s[0];
+        for (int k = 0; k < nt; ++k) {
+            const int kn = k + 1 < nt ? k + 1 : k;                       // the NEXT step's record, asked for now
+            T nxt[DRIVE_STRIDE - 1];
+#pragma unroll
+            for (int j = 0; j < DRIVE_STRIDE - 1; ++j) nxt[j] = drv[kn * DRIVE_STRIDE + j];
+            const int rowvn = row_s[kn];
+            member_step<T, L>(kl, cur, rr, qq, Rv, Sv, Cv, Tn);
+            const int row = __builtin_amdgcn_readfirstlane(rowv);
+            if (row >= 0 && row < n_rows && active) {
+                if (C_traj != nullptr) {
+                    T* c = C_traj + (int64_t)row * L::G * ld + m;
+#pragma unroll
+                    for (int g = 0; g < L::G; ++g) c[g * ld] = Cv[g];
+                }
+                if (T_traj != nullptr) T_traj[(int64_t)row * ld + m] = Tn;
+            }
+#pragma unroll
+            for (int j = 0; j < DRIVE_STRIDE - 1; ++j) cur[j] = nxt[j];
+            rowv = rowvn;
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < L::SP; ++k) R[k * ld + m] = Rv[k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) S[k * ld + m] = Sv[k];
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // LDS counter increment with ONE round of wave-level aggregation (the histogram passes and the pick pass).  In the first decades of a run every member's T sits in a
 // handful of bins: 64 lanes adding to the same LDS dword serialise (the first two 64-step chunks of a streamed run took

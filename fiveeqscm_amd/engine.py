@@ -44,11 +44,12 @@ PER_STEP_BLOCK = 25                  # steps enqueued per part before switching 
 FUSED_SPAN_STEPS = 128               # mode='fused': steps per launch for ensembles of few rounds of waves (see fused_span)
 FUSED_SPAN_MAX_ROUNDS = 8.0          # ... up to this many rounds of 4 waves per SIMD
 FUSED_SPAN_MIN_ROUNDS = 0.25         # ... and from this many on
-# mode='auto' takes the small-ensemble kernel (include/fiveeq.h, fiveeq_run_small_*) for single-gas layouts: one member per
+# mode='auto' takes the small-ensemble kernel (include/fiveeq.h, fiveeq_run_small_*): for a lone 4-pool gas one member per
 # QUAD of lanes while the quads' waves get a SIMD each (one 256-thread workgroup per CU: 64 members per CU, 16384 on an
 # MI355X; past that two waves share a SIMD and the unspread form is ahead), one member per lane up to this many members
 # (fp64 CO2-only, us per step: 0.42 / 0.54 / 0.73 quad / one lane / fused kernel at 10k members, 0.92 / 1.04 one lane /
-# fused at 100k, a tie at 130k: profiles/r05/small_ensemble_ab.txt)
+# fused at 100k, a tie at 130k; three gases: 0.94 / 1.38 at 10k, 1.65 / 1.93 at 100k, a tie at 200k:
+# profiles/r05/small_ensemble_ab.txt, small_ensemble_multigas_ab.txt)
 SMALL_ONE_LANE_MAX_MEMBERS = 100_000
 SMALL_QUAD_MEMBERS_PER_CU = 64
 
@@ -112,8 +113,8 @@ class EnsembleEngine(CheckpointMixin):
         long tail; relaunching the same kernel resets the ages (the state crosses HBM once per span: nothing at 128 steps).
         "auto": FUSED_SPAN_STEPS when the ensemble is between FUSED_SPAN_MIN_ROUNDS and FUSED_SPAN_MAX_ROUNDS rounds of resident
         waves, else one launch (profiles/r03/relaunch_sweep.txt).  Bit-identical either way.
-        small_lanes: mode='small' (single-gas layouts, no statistics / histograms): lanes per member, 4 (a lone 4-pool gas:
-        one pool per lane of a quad), 1, or "auto" = 4 while every quad wave gets a SIMD of its own, else 1."""
+        small_lanes: mode='small' (no statistics / histograms): lanes per member, 4 (a lone 4-pool gas: one pool per lane of a
+        quad), 1 (any layout), or "auto" = 4 where the layout has it and every quad wave gets a SIMD of its own, else 1."""
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.lib = _capi.load(lib_path)    # raises if the HIP library is not built
@@ -253,8 +254,8 @@ class EnsembleEngine(CheckpointMixin):
         return int(min(32, max(2, round(3.0 * LAUNCH_BOUNDARY_S / max(t_step, 1e-9)))))
 
     def small_form(self):
-        """Lanes per member mode='small' would run with now (4 or 1); 0 = the small-ensemble kernel does not apply: several
-        gases, or a run that wants per-wave statistics, in-loop histograms or the concentration-driven form."""
+        """Lanes per member mode='small' would run with now (4 or 1); 0 = the small-ensemble kernel does not apply: a run that
+        wants per-wave statistics, in-loop histograms or the concentration-driven form."""
         if not self.small_widest or self.collect_stats or self.T_hist is not None or self.concentration_driven:
             return 0
         if self.small_lanes != "auto":
@@ -362,8 +363,8 @@ class EnsembleEngine(CheckpointMixin):
                    filled by the streamed pipeline, see __init__);
         'ksteps'   the fused kernel over consecutive spans of `k_steps` steps (default `auto_k_steps()`):
                    state crosses HBM once per k_steps — the per-step family's answer for launch-bound ensembles;
-        'small'    the small-ensemble kernel (single-gas layouts; see small_lanes): one member per quad of lanes, the model in
-                   registers, one launch;
+        'small'    the small-ensemble kernel (see small_lanes): the model in registers, one launch; a lone 4-pool gas: one member
+                   per quad of lanes;
         'auto'     see resolve_mode().
         Every mode gives bit-identical results.
         join=False (mode 'per_step' on several streams only): do not make the caller's stream wait for the side streams at
@@ -380,8 +381,8 @@ class EnsembleEngine(CheckpointMixin):
         if self.T_hist is not None and mode not in ("fused", "per_step"):
             raise ValueError(f"mode {mode!r} does not fill T_hist: use 'fused' or 'per_step' with hist=")
         if mode == "small" and not self.small_form():
-            raise ValueError("mode 'small' serves single-gas layouts without statistics, histograms or the inverse form "
-                             f"(pools {self.pools}, small_lanes={self.small_lanes!r})")
+            raise ValueError("mode 'small' serves runs without statistics, histograms or the inverse form, with 4 lanes per "
+                             f"member for a lone 4-pool gas only (pools {self.pools}, small_lanes={self.small_lanes!r})")
         with torch.cuda.device(self.device):
             self._wave_stats()
             self._step_sums_valid[t_begin:t_end] = False     # these launches write per-wave records: older folded sums are stale

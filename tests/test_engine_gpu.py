@@ -394,9 +394,11 @@ def test_auto_takes_the_small_ensemble_kernel_where_the_measured_table_says(gpu)
     assert _engine(p, 5000, E).resolve_mode("auto", 7) == ("ksteps", 7)               # an explicit K is taken as given
     pm = prm.sample_ensemble(prm.default_params("multigas"), 5000)
     em = _engine(pm, 5000, emi.rcp_like_emissions(30, 3))
-    assert em.small_widest == 0 and em.resolve_mode("auto")[0] == "ksteps"
-    with pytest.raises(ValueError, match="single-gas"):
-        em.run(mode="small")
+    assert em.small_widest == 1 and em.resolve_mode("auto")[0] == "small" and em.small_form() == 1     # three gases: one lane
+    with pytest.raises(ValueError, match="small"):
+        _engine(pm, 5000, emi.rcp_like_emissions(30, 3), small_lanes=4).run(mode="small")
+    with pytest.raises(ValueError, match="small"):
+        _engine(pm, 5000, emi.rcp_like_emissions(30, 3), collect_stats=True).run(mode="small")
 
 
 def test_packed_fp32_lanes_equal_scalar_lanes_bit_for_bit(gpu):
@@ -613,12 +615,22 @@ def test_all_compiled_layouts_match_oracle(gpu):
         p = prm.sample_ensemble(p, N, seed=3)
         E = emi.rcp_like_emissions(n_steps, G)
         want = npo.run(E, p, N)
-        for mode in ("per_step", "fused"):
+        first = None
+        for mode in ("per_step", "fused", "small"):                   # (small: every layout has the one-lane form)
             eng = _engine(p, N, E)
             eng.run(mode=mode)
             torch.cuda.synchronize()
             _close(eng.C, want["C"], what=f"C {pools} {mode}")
             _close(eng.T, want["T"], what=f"T {pools} {mode}")
+            if first is None:
+                first = (eng.C.clone(), eng.T.clone(), eng.R.clone(), eng.S.clone())
+            for x, y in zip(first, (eng.C, eng.T, eng.R, eng.S)):
+                assert torch.equal(x, y), (pools, mode)                   # and all three are one arithmetic, bit for bit
+        e32 = [_engine(p, N, E, dtype=torch.float32) for _ in range(2)]
+        e32[0].run(mode="per_step")
+        e32[1].run(mode="small")
+        torch.cuda.synchronize()
+        assert torch.equal(e32[0].C, e32[1].C) and torch.equal(e32[0].T, e32[1].T) and torch.equal(e32[0].R, e32[1].R), pools
 
 
 def test_random_models_and_scenarios_match_oracle(gpu):
@@ -882,9 +894,9 @@ def test_randomized_launch_shapes_and_histogram_specs(gpu):
         state = ref.state_dict(include_outputs=False)
         ref.run(t0, t1, mode="fused")
         want_hist = ref.T_histogram(lo, hi, nb, rows=list(range(t0, t1)))
-        forms = [("fused", None), ("per_step", None), ("ksteps", int(rng.integers(1, 20)))]
-        if G == 1:                                                    # the small-ensemble kernel: single-gas layouts, no statistics
-            forms += [("small", 1), ("small", 4)]
+        forms = [("fused", None), ("per_step", None), ("ksteps", int(rng.integers(1, 20))), ("small", 1)]
+        if G == 1:                                                    # one member per quad of lanes: a lone 4-pool gas
+            forms += [("small", 4)]
         for mode, k_use in forms:
             plain = mode in ("ksteps", "small")                       # forms that do not fill T_hist
             eng = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=mode != "small",

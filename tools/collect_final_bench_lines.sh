@@ -17,6 +17,8 @@ for S in a c; do eval C=\$SQ$(echo $S | tr a-z A-Z); timeout -k 10 300 rocprofv3
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_step_f32_4M.csv $OUT/valu.json 1 $OUT/pmc_sqa_step32 $OUT/pmc_sqc_step32 > /dev/null
 for S in a b; do eval C=\$SQ$(echo $S | tr a-z A-Z); timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_sq${S}_small -- python3 $R/tools/pmc_workload_fused.py 10000 f64 750 co2 small > $OUT/pmc_sq${S}_small.log 2>&1; echo "small $S"; done
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_small_co2_f64_10k.csv $OUT/valu.json 750 $OUT/pmc_sqa_small $OUT/pmc_sqb_small > /dev/null
+timeout -k 10 300 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_small3 -- python3 $R/tools/pmc_workload_fused.py 10000 f64 750 multigas small > $OUT/pmc_sqa_small3.log 2>&1
+python3 $R/tools/pmc_valu.py $OUT/sq_counters_small_multigas_f64_10k.csv $OUT/valu.json 750 $OUT/pmc_sqa_small3 > /dev/null
 cp $OUT/valu.json $R/profiles/valu.json
 cd $R
 python3 bench.py > $OUT/bench_config3.json 2> $OUT/bench_config3.err; echo bench1

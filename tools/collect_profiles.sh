@@ -48,6 +48,8 @@ python3 $R/tools/pmc_valu.py $OUT/sq_counters_co2_f64_1M.csv $OUT/valu.json 96 $
 timeout -k 10 400 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_small -- python3 $R/tools/pmc_workload_fused.py 10000 f64 750 co2 small > $OUT/pmc_sqa_small.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OUT/pmc_sqb_small -- python3 $R/tools/pmc_workload_fused.py 10000 f64 750 co2 small > $OUT/pmc_sqb_small.log 2>&1
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_small_co2_f64_10k.csv $OUT/valu.json 750 $OUT/pmc_sqa_small $OUT/pmc_sqb_small > /dev/null
+timeout -k 10 400 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_small3 -- python3 $R/tools/pmc_workload_fused.py 10000 f64 750 multigas small > $OUT/pmc_sqa_small3.log 2>&1
+python3 $R/tools/pmc_valu.py $OUT/sq_counters_small_multigas_f64_10k.csv $OUT/valu.json 750 $OUT/pmc_sqa_small3 > /dev/null
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_config2 -- python3 $R/bench.py --workload config2 --mode auto --no-cpu-baseline \
     > $OUT/bench_config2_auto_under_rocprof.json 2> $OUT/trace_config2.err || echo "config2 trace failed"
 echo "== the streamed histogram pipeline under --kernel-trace --stats; LDS conflicts of the histogram kernels; fused traffic =="

@@ -49,8 +49,11 @@ def main():
         # fused_kernel<V, P0, P1, P2, INV, BINS>: the plain forward form only
         ms = re.match(r"fiveeq::small_kernel<(double|float), (\d), (\d)>", k)       # <T, P0, lanes per member>: single-gas layouts
         m = re.match(r"fiveeq::(step|fused)_kernel<(double|float2|float), (\d), (\d), (\d)((?:, (?:true|false))*)>", k)
+        mm_ = re.match(r"fiveeq::small_multi_kernel<(double|float), (\d), (\d), (\d)>", k)   # several gases: one lane per member
         if ms:
             m = re.match(r"(small) (\w+) (\d) (0) (0)()", f"small {ms.group(1)} {ms.group(2)} 0 0")
+        if mm_:
+            m = re.match(r"(small) (\w+) (\d) (\d) (\d)()", f"small {mm_.group(1)} {mm_.group(2)} {mm_.group(3)} {mm_.group(4)}")
         if not m or "true" in m.group(6):
             continue
         mean = lambda c: (sum(acc[(k, c)]) / len(acc[(k, c)])) if (k, c) in acc else None   # noqa: E731
@@ -64,6 +67,8 @@ def main():
         if ms:
             per_wave = 64 // int(ms.group(3))                       # a quad of lanes per member: 16 members per wave
             key += f":{ms.group(3)}"
+        if mm_:
+            key += ":1"
         rec = {"kernel": k, "valu_per_wave_step": valu / waves / steps, "members_per_wave": per_wave,
                "valu_per_member_step": valu / waves / steps / per_wave, "waves": waves, "steps_per_launch": steps,
                "dispatches": len(acc[(k, "SQ_INSTS_VALU")])}

@@ -22,7 +22,7 @@ p = params.sample_ensemble_shard(params.default_params(kind), N, device="cuda:0"
 E = emissions.rcp_like_emissions(max(750, 250 + STEPS), 3 if kind == "multigas" else 1)[250:250 + STEPS]
 assert E.shape[0] == STEPS
 if small:
-    for lanes in (4, 1):
+    for lanes in ((4, 1) if kind == "co2" else (1,)):
         eng = EnsembleEngine(p, N, E, dtype=dt, device="cuda:0", small_lanes=lanes)       # trajectories stored, like config 2
         for _ in range(3):
             eng.reset_state()

@@ -15,20 +15,23 @@ from fiveeqscm_amd import emissions, params  # noqa: E402
 from fiveeqscm_amd.engine import EnsembleEngine  # noqa: E402
 
 dtype = torch.float32 if "--f32" in sys.argv else torch.float64
+kind, G = ("multigas", 3) if "--multigas" in sys.argv else ("co2", 1)
 sizes = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [10_000, 20_000, 40_000, 80_000, 160_000, 320_000]
-E = emissions.rcp_like_emissions(750, 1)
-print(f"# {torch.cuda.get_device_name(0)}, dtype {dtype}, CO2-only, 750 steps, trajectories stored; us per step (median of 7 passes)")
+E = emissions.rcp_like_emissions(750, G)
+print(f"# {torch.cuda.get_device_name(0)}, dtype {dtype}, {kind}, 750 steps, trajectories stored; us per step (median of 7 passes)")
 print(f"# {'members':>8} {'fused':>8} {'fused1':>8} {'ksteps':>8} {'small1':>8} {'small4':>8}   small4 member-steps/s   equal")
 for N in sizes:
-    p = params.sample_ensemble_shard(params.default_params("co2"), N, device="cuda:0", dtype=dtype)
+    p = params.sample_ensemble_shard(params.default_params(kind), N, device="cuda:0", dtype=dtype)
     eng = EnsembleEngine(p, N, E, dtype=dtype)
     eng.run(mode="per_step")
     torch.cuda.synchronize()
     ref = [eng.C.clone(), eng.T.clone(), eng.R.clone(), eng.S.clone()]
     out, same = {}, True
-    for name, mode, kw in (("fused", "fused", {}), ("fused1", "fused", {"span": None}), ("ksteps", "ksteps", {}),
-                           ("small1", "small", {"lanes": 1}), ("small4", "small", {"lanes": 4})):
-        eng.small_lanes = kw.get("lanes", 0)
+    forms = [("fused", "fused", {}), ("fused1", "fused", {"span": None}), ("ksteps", "ksteps", {}), ("small1", "small", {"lanes": 1})]
+    forms += [("small4", "small", {"lanes": 4})] if eng.small_widest == 4 else []
+    out["small4"] = float("nan")
+    for name, mode, kw in forms:
+        eng.small_lanes = kw.get("lanes", "auto")
         eng.fused_span = kw.get("span", "auto")
         ts = []
         for rep in range(8):
