@@ -93,8 +93,8 @@ SIGNATURES = {
     "fiveeq_run_inverse_f32": (ctypes.c_int, _RUN_ARGS[:11] + [_p] + _RUN_ARGS[11:]),
     "fiveeq_run_ksteps_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
     "fiveeq_run_ksteps_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
-    "fiveeq_run_small_f64": (ctypes.c_int, _RUN_ARGS[:-2] + [_i32, _p]),
-    "fiveeq_run_small_f32": (ctypes.c_int, _RUN_ARGS[:-2] + [_i32, _p]),
+    "fiveeq_run_small_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
+    "fiveeq_run_small_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
     "fiveeq_small_lanes": (_i32, [_i32, ctypes.POINTER(_i32)]),
     "fiveeq_set_f32_packing": (ctypes.c_int, [ctypes.c_int]),
     "fiveeq_lhs_rows_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p, _p]),

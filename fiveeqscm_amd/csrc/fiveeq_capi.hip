@@ -348,10 +348,10 @@ int small_lanes(int code) { return code == 400 ? 4 : (layout_ok(code) ? 1 : 0); 
 
 template <typename T>
 int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
-              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, int32_t lanes,
-              void* stream) {
+              int32_t t_end, const T* r, const T* q, T* R, T* S, T* C_traj, T* T_traj, int n_rows, double* stats,
+              int32_t lanes, void* stream) {
     RunArgs<T> a;
-    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, nullptr)) return rc;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
     const int widest = small_lanes(a.code);
     if (lanes == 0) lanes = widest;
     if (lanes != 1 && lanes != widest)
@@ -362,7 +362,7 @@ int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_SMALL_BLOCK);
     hipStream_t st = (hipStream_t)stream;
-#define FIVEEQ_SMALL_ARGS st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows
+#define FIVEEQ_SMALL_ARGS st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats
     switch (a.code * 10 + lanes) {
         case 1001: hipLaunchKernelGGL((small_kernel<T, 1, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
         case 2001: hipLaunchKernelGGL((small_kernel<T, 2, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
@@ -593,14 +593,16 @@ int fiveeq_run_ksteps_f32(const fiveeq_model* model, int64_t n_members, int64_t 
 }
 int fiveeq_run_small_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
                          int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,
-                         double* S, double* C_traj, double* T_traj, int32_t n_rows, int32_t lanes_per_member, void* stream) {
-    return run_small<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                         double* S, double* C_traj, double* T_traj, int32_t n_rows, double* T_stats, int32_t lanes_per_member,
+                         void* stream) {
+    return run_small<double>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
                              lanes_per_member, stream);
 }
 int fiveeq_run_small_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive,
                          int32_t n_steps, int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R,
-                         float* S, float* C_traj, float* T_traj, int32_t n_rows, int32_t lanes_per_member, void* stream) {
-    return run_small<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
+                         float* S, float* C_traj, float* T_traj, int32_t n_rows, double* T_stats, int32_t lanes_per_member,
+                         void* stream) {
+    return run_small<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
                             lanes_per_member, stream);
 }
 int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t* n_pools) {

@@ -1025,8 +1025,8 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
 //     nothing hides is ~100 cycles of the wave's time;
 //   * the step's drive record is read one step AHEAD (LDS, broadcast), so that its latency lies under the previous step.
 // LPM = 1 is the same kernel without the spreading (any single-gas layout): what the register-resident constants buy alone.
-// No per-wave statistics and no histogram ring: those runs take the fused kernel.  Same arithmetic, operation for
-// operation, as member_step(): bit-identical results (tested against the per-step path).
+// Per-wave statistics as in the fused kernel (the same records, bit for bit); no histogram ring: those runs take the fused
+// kernel.  Same arithmetic, operation for operation, as member_step(): bit-identical results (tested against the per-step path).
 // ---------------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ double quad_bcast(const double v) {           // lane 4q + K of every quad, to the whole quad
@@ -1045,11 +1045,21 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
     const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
     const int64_t n, const int64_t ld, const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R,
     T* __restrict__ S, T* __restrict__ C_traj /* [n_rows][1][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
-    const int n_rows) {
+    const int n_rows, double* __restrict__ stats /* [ceil(n/64)][n_steps][4] or nullptr */) {
     static_assert(LPM == 1 || (LPM == 4 && P0 == 4), "a quad of lanes carries the four pools of one gas");
+    static_assert(LPM == 1 || FIVEEQ_SMALL_BLOCK == 256, "quad form: one workgroup = 64 members = one statistics record");
     constexpr int MPB = FIVEEQ_SMALL_BLOCK / LPM;                        // members per workgroup
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
     __shared__ int row_s[FIVEEQ_FUSED_CHUNK];                            // the steps' output rows, converted once per chunk
+    // per-64-member statistics records, batched over STAT_STEPS steps and folded by wave_stats_flush() exactly like the fused
+    // kernel's (same tile layout, same order: the same record bits).  One lane per member: a tile per wave.  A quad per member:
+    // the workgroup's four waves hold 16 members each = ONE record; they share a tile and wave 0 folds it between two barriers.
+    __shared__ T stat_tile[LPM == 1 ? FIVEEQ_SMALL_BLOCK / 64 : 1][STAT_STEPS * STAT_ROW];
+    const int64_t rec = LPM == 1 ? (int64_t)blockIdx.x * (FIVEEQ_SMALL_BLOCK / 64) + (threadIdx.x >> 6) : (int64_t)blockIdx.x;
+    const bool rec_live = stats != nullptr && rec < ((n + 63) >> 6);      // uniform over the wave (LPM = 1) / the workgroup (LPM = 4)
+    const int n_valid = (int)min((int64_t)64, n - rec * 64);
+    T* const tile = stat_tile[LPM == 1 ? threadIdx.x >> 6 : 0];
+    int ks = 0;
     const int lane = threadIdx.x;
     const int sub = lane % LPM;                                          // the pool this lane carries (LPM = 4)
     const int64_t m = (int64_t)blockIdx.x * MPB + lane / LPM;
@@ -1160,6 +1170,20 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
                     if (out_q != nullptr) out_q[(int64_t)row * ld] = sub == 0 ? Cg : Tn;
                 }
             }
+            if (rec_live) {
+                if (LPM == 1 || sub == 0) tile[ks * STAT_ROW + (LPM == 1 ? (threadIdx.x & 63) : (threadIdx.x >> 2))] = Tn;
+                if (++ks == STAT_STEPS || tc + k + 1 == t_end) {
+                    double* const out = stats + (rec * n_steps + (tc + k + 1 - ks)) * 4;
+                    if constexpr (LPM == 1) {
+                        wave_stats_flush(tile, ks, n_valid, out, 4);
+                    } else {
+                        __syncthreads();
+                        if (threadIdx.x < 64) wave_stats_flush(tile, ks, n_valid, out, 4);
+                        __syncthreads();
+                    }
+                    ks = 0;
+                }
+            }
             E = En, cumE = cumEn, Fx = Fxn, rowv = rowvn;
         }
     }
@@ -1186,10 +1210,16 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
     const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
     const int64_t n, const int64_t ld, const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R,
     T* __restrict__ S, T* __restrict__ C_traj /* [n_rows][G][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
-    const int n_rows) {
+    const int n_rows, double* __restrict__ stats /* [ceil(n/64)][n_steps][4] or nullptr */) {
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
     __shared__ int row_s[FIVEEQ_FUSED_CHUNK];
+    __shared__ T stat_tile[FIVEEQ_SMALL_BLOCK / 64][STAT_STEPS * STAT_ROW];          // statistics: as in small_kernel, one lane per member
+    const int64_t rec = (int64_t)blockIdx.x * (FIVEEQ_SMALL_BLOCK / 64) + (threadIdx.x >> 6);
+    const bool rec_live = stats != nullptr && rec < ((n + 63) >> 6);
+    const int n_valid = (int)min((int64_t)64, n - rec * 64);
+    T* const tile = stat_tile[threadIdx.x >> 6];
+    int ks = 0;
     // fp64: the model, word by word, into VECTOR registers.  Left to itself the compiler keeps the ~45 constants of three
     // gases in scalar registers, runs out of them (two each) and spills — 83 v_readlane per step, 1.25 us per step instead of
     // 0.94 at 10k members (r05/ab_variants.txt section 4).  fp32 constants fit the scalar file and stay there (0.51 against 0.61).
@@ -1245,6 +1275,13 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
                     for (int g = 0; g < L::G; ++g) c[g * ld] = Cv[g];
                 }
                 if (T_traj != nullptr) T_traj[(int64_t)row * ld + m] = Tn;
+            }
+            if (rec_live) {
+                tile[ks * STAT_ROW + (threadIdx.x & 63)] = Tn;
+                if (++ks == STAT_STEPS || tc + k + 1 == t_end) {
+                    wave_stats_flush(tile, ks, n_valid, stats + (rec * n_steps + (tc + k + 1 - ks)) * 4, 4);
+                    ks = 0;
+                }
             }
 #pragma unroll
             for (int j = 0; j < DRIVE_STRIDE - 1; ++j) cur[j] = nxt[j];

@@ -113,7 +113,7 @@ class EnsembleEngine(CheckpointMixin):
         long tail; relaunching the same kernel resets the ages (the state crosses HBM once per span: nothing at 128 steps).
         "auto": FUSED_SPAN_STEPS when the ensemble is between FUSED_SPAN_MIN_ROUNDS and FUSED_SPAN_MAX_ROUNDS rounds of resident
         waves, else one launch (profiles/r03/relaunch_sweep.txt).  Bit-identical either way.
-        small_lanes: mode='small' (no statistics / histograms): lanes per member, 4 (a lone 4-pool gas: one pool per lane of a
+        small_lanes: mode='small' (no in-loop histograms): lanes per member, 4 (a lone 4-pool gas: one pool per lane of a
         quad), 1 (any layout), or "auto" = 4 where the layout has it and every quad wave gets a SIMD of its own, else 1."""
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
@@ -255,8 +255,8 @@ class EnsembleEngine(CheckpointMixin):
 
     def small_form(self):
         """Lanes per member mode='small' would run with now (4 or 1); 0 = the small-ensemble kernel does not apply: a run that
-        wants per-wave statistics, in-loop histograms or the concentration-driven form."""
-        if not self.small_widest or self.collect_stats or self.T_hist is not None or self.concentration_driven:
+        wants in-loop histograms or the concentration-driven form."""
+        if not self.small_widest or self.T_hist is not None or self.concentration_driven:
             return 0
         if self.small_lanes != "auto":
             return self.small_lanes if self.small_lanes in (1, self.small_widest) else 0
@@ -381,7 +381,7 @@ class EnsembleEngine(CheckpointMixin):
         if self.T_hist is not None and mode not in ("fused", "per_step"):
             raise ValueError(f"mode {mode!r} does not fill T_hist: use 'fused' or 'per_step' with hist=")
         if mode == "small" and not self.small_form():
-            raise ValueError("mode 'small' serves runs without statistics, histograms or the inverse form, with 4 lanes per "
+            raise ValueError("mode 'small' serves runs without in-loop histograms or the inverse form, with 4 lanes per "
                              f"member for a lone 4-pool gas only (pools {self.pools}, small_lanes={self.small_lanes!r})")
         with torch.cuda.device(self.device):
             self._wave_stats()
@@ -404,7 +404,7 @@ class EnsembleEngine(CheckpointMixin):
                 k = self.auto_k_steps() if k_steps is None else int(k_steps)
                 rc = self._fn("run_ksteps")(*self._run_args(t_begin, t_end), max(k, 1), self._stream(stream))
             elif mode == "small":
-                rc = self._fn("run_small")(*self._run_args(t_begin, t_end)[:-1], self.small_form(), self._stream(stream))
+                rc = self._fn("run_small")(*self._run_args(t_begin, t_end), self.small_form(), self._stream(stream))
             else:                                                # 'graph': one captured plan per (chunk, part), the parts of a
                 plans = self.prepare_graph(t_begin, t_end)       # chunk replayed side by side on their own streams
                 rc = self._on_part_streams(stream, True, lambda streams: self._first_error(

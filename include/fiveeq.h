@@ -208,18 +208,19 @@ int fiveeq_run_ksteps_f32(const fiveeq_model *model, int64_t n_members, int64_t 
  * per-step kernel's order ((R0 + R1) + R2) + R3 — and the shared model stays in registers instead of LDS.  4x the waves of
  * fiveeq_run_fused_*, 16 members per wave.  lanes_per_member: 4, 1 (one member per lane with the model in registers: every
  * compiled layout, several gases included) or 0 = the widest form the layout has (fiveeq_small_lanes).  One launch for the
- * whole span; C_traj, T_traj and the row map as in the other entry points; NO per-wave statistics (such runs take
- * fiveeq_run_fused_* / fiveeq_run_ksteps_*).  Same arithmetic operation for operation: bit-identical results to the
- * per-step path.  Ahead of the fused kernel up to ~100k members (10k members, us per step: CO2-only fp64 0.42 against 0.73,
+ * whole span; C_traj, T_traj, the row map and T_stats as in the other entry points (the statistics records are the fused
+ * kernel's bit for bit).  Same arithmetic operation for operation: bit-identical results to the per-step path.  Ahead of the fused kernel up to ~100k members (10k members, us per step: CO2-only fp64 0.42 against 0.73,
  * three gases fp64 0.94 against 1.38, fp32 0.51 against 1.16). */
 int fiveeq_run_small_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
                          const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
                          const double *r, const double *q, double *R, double *S,
-                         double *C_traj, double *T_traj, int32_t n_rows, int32_t lanes_per_member, void *stream);
+                         double *C_traj, double *T_traj, int32_t n_rows, double *T_stats,
+                         int32_t lanes_per_member, void *stream);
 int fiveeq_run_small_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
                          const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
                          const float *r, const float *q, float *R, float *S,
-                         float *C_traj, float *T_traj, int32_t n_rows, int32_t lanes_per_member, void *stream);
+                         float *C_traj, float *T_traj, int32_t n_rows, double *T_stats,
+                         int32_t lanes_per_member, void *stream);
 /* lanes per member of the widest small-ensemble form compiled for (n_gas, n_pools[]): 4 (a lone 4-pool gas), 1 (every other
  * compiled layout), or 0 = the layout has no kernel at all */
 int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t *n_pools);

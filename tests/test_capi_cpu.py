@@ -198,7 +198,7 @@ def test_new_entry_points_validate_on_the_host():
     lanes = lambda *pl: lib.fiveeq_small_lanes(len(pl), (ctypes.c_int32 * len(pl))(*pl))   # noqa: E731
     assert [lanes(4), lanes(1), lanes(2), lanes(3), lanes(4, 1, 1), lanes(1, 1), lanes(4, 4, 4), lanes(5), lanes(2, 3)] == [4, 1, 1, 1, 1, 1, 1, 0, 0]
     small = lambda model, n_lanes, t0=0, t1=4: lib.fiveeq_run_small_f64(ctypes.byref(model), 8, 8, p, 4, t0, t1, p, p, p, p, None,   # noqa: E731
-                                                                       None, 0, n_lanes, None)
+                                                                       None, 0, None, n_lanes, None)
     assert small(m, 4) == _capi.E_INVALID and b"lanes_per_member" in lib.fiveeq_last_error()    # three gases: one lane only
     assert small(m, 0, 2, 2) == _capi.OK and small(m, 1, 2, 2) == _capi.OK
     co2 = prm.make_model(prm.default_params("co2"))
@@ -207,9 +207,9 @@ def test_new_entry_points_validate_on_the_host():
     assert small(co2, 4, 3, 2) == _capi.E_INVALID                      # the shared checks: step range
     for n_lanes in (0, 1, 4):
         assert small(co2, n_lanes, 2, 2) == _capi.OK                   # empty span: nothing to launch
-    assert lib.fiveeq_run_small_f32(ctypes.byref(co2), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, 0, None) == _capi.OK
+    assert lib.fiveeq_run_small_f32(ctypes.byref(co2), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, None, 0, None) == _capi.OK
     one_pool = dict(prm.default_params("co2"))
-    bad = lib.fiveeq_run_small_f64(ctypes.byref(co2), 8, 8, None, 4, 0, 4, p, p, p, p, None, None, 0, 0, None)
+    bad = lib.fiveeq_run_small_f64(ctypes.byref(co2), 8, 8, None, 4, 0, 4, p, p, p, p, None, None, 0, None, 0, None)
     assert bad == _capi.E_INVALID and b"NULL" in lib.fiveeq_last_error() and one_pool
 
 

@@ -367,7 +367,7 @@ def test_small_ensemble_kernel_ragged_sizes_layouts_and_resume(gpu):
     for m0, n in ((0, 999), (128, 129), (1, 998), (333, 64), (999, 1)):
         for lanes in (1, 4):
             eng = _engine(p, N, E)
-            rc = lib.fiveeq_run_small_f64(*eng._run_args(0, n_steps, m0, n)[:-1], lanes, eng._stream())
+            rc = lib.fiveeq_run_small_f64(*eng._run_args(0, n_steps, m0, n), lanes, eng._stream())
             assert rc == 0, lib.fiveeq_last_error()
             torch.cuda.synchronize()
             assert torch.equal(eng.T[:, m0:m0 + n], ref.T[:, m0:m0 + n]) and torch.equal(eng.R[:, m0:m0 + n], ref.R[:, m0:m0 + n])
@@ -389,7 +389,7 @@ def test_auto_takes_the_small_ensemble_kernel_where_the_measured_table_says(gpu)
         assert eng.resolve_mode("auto")[0] == mode and (mode != "small" or eng.small_form() == lanes), (N, mode, lanes)
         eng.close()
     p = prm.sample_ensemble(prm.default_params("co2"), 5000)
-    assert _engine(p, 5000, E, collect_stats=True).resolve_mode("auto")[0] == "ksteps"
+    assert _engine(p, 5000, E, collect_stats=True).resolve_mode("auto")[0] == "small"                # statistics ride along
     assert _engine(p, 5000, E, hist=(-1.0, 5.0, 64)).resolve_mode("auto")[0] == "fused"
     assert _engine(p, 5000, E).resolve_mode("auto", 7) == ("ksteps", 7)               # an explicit K is taken as given
     pm = prm.sample_ensemble(prm.default_params("multigas"), 5000)
@@ -398,7 +398,7 @@ def test_auto_takes_the_small_ensemble_kernel_where_the_measured_table_says(gpu)
     with pytest.raises(ValueError, match="small"):
         _engine(pm, 5000, emi.rcp_like_emissions(30, 3), small_lanes=4).run(mode="small")
     with pytest.raises(ValueError, match="small"):
-        _engine(pm, 5000, emi.rcp_like_emissions(30, 3), collect_stats=True).run(mode="small")
+        _engine(pm, 5000, emi.rcp_like_emissions(30, 3), hist=(-1.0, 5.0, 64)).run(mode="small")
 
 
 def test_packed_fp32_lanes_equal_scalar_lanes_bit_for_bit(gpu):
@@ -812,6 +812,38 @@ def test_on_device_stats_match_trajectory(gpu, mode, N):
     assert torch.equal(eng2.T_stats, eng.T_stats)
 
 
+def test_small_ensemble_kernels_write_the_fused_kernels_statistics_records(gpu):
+    """The small-ensemble kernels batch T over 8 steps and fold it with the fused kernel's own routine — a tile per wave (one
+    lane per member), or one tile per workgroup whose four waves hold 16 members each (a quad per member) — so the per-64-member
+    records are the fused kernel's BIT FOR BIT: ragged ensembles (a last record with 1 ... 63 members, a workgroup with idle
+    waves), step ranges that are not multiples of 8, a run resumed mid-way, both precisions, one and three gases."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(21)
+    n_steps = 131                                                    # one 125-step drive chunk + a ragged rest
+    for kind, G in (("co2", 1), ("multigas", 3)):
+        E = emi.rcp_like_emissions(750, G)[210:210 + n_steps]
+        for N in (1, 15, 17, 63, 64, 65, 255, 256, 257, 1000, 4097):
+            for td in (torch.float64, torch.float32):
+                p = prm.sample_ensemble(prm.default_params(kind), N, seed=N)
+                ref = _engine(p, N, E, dtype=td, collect_stats=True, store_trajectory=False)
+                lib.fiveeq_set_f32_packing(0)                        # (packed fp32 lanes fold a record's sums in another order)
+                try:
+                    ref.run(mode="fused")
+                finally:
+                    lib.fiveeq_set_f32_packing(1)
+                for lanes in ((4, 1) if G == 1 else (1,)):
+                    eng = _engine(p, N, E, dtype=td, collect_stats=True, store_trajectory=False, small_lanes=lanes)
+                    cut = int(rng.integers(1, n_steps))
+                    eng.run(0, cut, mode="small")
+                    eng.run(cut, n_steps, mode="small")
+                    torch.cuda.synchronize()
+                    assert torch.equal(eng.T_stats, ref.T_stats), (kind, N, td, lanes, cut)
+                    assert torch.equal(eng.R, ref.R) and torch.equal(eng.S, ref.S), (kind, N, td, lanes)
+                    eng.close()
+                ref.close()
+
+
 @pytest.mark.parametrize("dtype,N", [("f64", 1), ("f64", 1023), ("f64", 1024), ("f64", 1025), ("f64", 70_001),
                                      ("f32", 300_007)])
 def test_in_loop_histograms_equal_histograms_of_stored_rows(gpu, dtype, N):
@@ -899,7 +931,7 @@ def test_randomized_launch_shapes_and_histogram_specs(gpu):
             forms += [("small", 4)]
         for mode, k_use in forms:
             plain = mode in ("ksteps", "small")                       # forms that do not fill T_hist
-            eng = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=mode != "small",
+            eng = _engine(p, N, E, dtype=td, store_concentrations=False, collect_stats=True,
                           hist=None if plain else (lo, hi, nb), hist_ring_steps=int(rng.integers(1, 12)),
                           small_lanes=k_use if mode == "small" else "auto")
             eng.load_state_dict(state)
@@ -911,10 +943,11 @@ def test_randomized_launch_shapes_and_histogram_specs(gpu):
             if not plain:
                 assert torch.equal(eng.T_hist[t0:t1], want_hist), what
                 assert int(eng.T_hist[:t0].sum()) == 0 and int(eng.T_hist[t1:].sum()) == 0, what
-            if mode != "small":
-                a, b = eng.stats_sums(t0, t1), ref.stats_sums(t0, t1)
-                assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]), what
-                assert torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-11, atol=1e-9), what
+            a, b = eng.stats_sums(t0, t1), ref.stats_sums(t0, t1)
+            assert torch.equal(a[:, [0, 3, 4]], b[:, [0, 3, 4]]), what
+            assert torch.allclose(a[:, 1:3], b[:, 1:3], rtol=1e-11, atol=1e-9), what
+            if mode == "small" and td == torch.float64:               # the fused kernel's records, bit for bit
+                assert torch.equal(eng.T_stats[:, t0:t1], ref.T_stats[:, t0:t1]), what
             eng.close()
         ref.close()
 
