@@ -766,7 +766,7 @@ def main():
         reps = -(-n_scen // span)
         k_avg = float(samples.mean())                           # seconds per model step inside the kernel
         achieved = A * n_local / k_avg / 1e9
-        kernel_name = ((f"fiveeq::small_kernel<{lname}>" if single else f"fiveeq::small_multi_kernel<{lname}>")
+        kernel_name = ((f"fiveeq::small_kernel<{lname},false>" if single else f"fiveeq::small_multi_kernel<{lname},false>")
                        if kname == "small_kernel" else f"fiveeq::{kname}<{lname},{pools3}>")
         roofline = {"bound": "fp64-valu" if a.dtype == "f64" else "fp32-valu", "unit": "wave-instr/s",
                     "achieved": None, "peak": valu_peak, "frac": None, "traffic": None,

@@ -363,20 +363,29 @@ int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     const dim3 grid((unsigned)blocks), block(FIVEEQ_SMALL_BLOCK);
     hipStream_t st = (hipStream_t)stream;
 #define FIVEEQ_SMALL_ARGS st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats
+    const bool st_on = a.stats != nullptr;
+#define FIVEEQ_SMALL1(p0, lpm)                                                                                     \
+    if (st_on) hipLaunchKernelGGL((small_kernel<T, p0, lpm, true>), grid, block, 0, FIVEEQ_SMALL_ARGS);            \
+    else hipLaunchKernelGGL((small_kernel<T, p0, lpm, false>), grid, block, 0, FIVEEQ_SMALL_ARGS);                 \
+    break;
     switch (a.code * 10 + lanes) {
-        case 1001: hipLaunchKernelGGL((small_kernel<T, 1, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
-        case 2001: hipLaunchKernelGGL((small_kernel<T, 2, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
-        case 3001: hipLaunchKernelGGL((small_kernel<T, 3, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
-        case 4001: hipLaunchKernelGGL((small_kernel<T, 4, 1>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
-        case 4004: hipLaunchKernelGGL((small_kernel<T, 4, 4>), grid, block, 0, FIVEEQ_SMALL_ARGS); break;
+        case 1001: FIVEEQ_SMALL1(1, 1)
+        case 2001: FIVEEQ_SMALL1(2, 1)
+        case 3001: FIVEEQ_SMALL1(3, 1)
+        case 4001: FIVEEQ_SMALL1(4, 1)
+        case 4004: FIVEEQ_SMALL1(4, 4)
 #define X(p0, p1, p2)                                                                                              \
     case ((p0) * 100 + (p1) * 10 + (p2)) * 10 + 1:                                                                 \
-        if constexpr ((p1) > 0) hipLaunchKernelGGL((small_multi_kernel<T, p0, p1, p2>), grid, block, 0, FIVEEQ_SMALL_ARGS); \
+        if constexpr ((p1) > 0) {                                                                                  \
+            if (st_on) hipLaunchKernelGGL((small_multi_kernel<T, p0, p1, p2, true>), grid, block, 0, FIVEEQ_SMALL_ARGS);  \
+            else hipLaunchKernelGGL((small_multi_kernel<T, p0, p1, p2, false>), grid, block, 0, FIVEEQ_SMALL_ARGS);       \
+        }                                                                                                          \
         break;
         X(1, 1, 0) X(4, 1, 0) X(4, 4, 0) X(1, 1, 1) X(4, 1, 1) X(4, 4, 1) X(4, 4, 4)
 #undef X
         default: return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
     }
+#undef FIVEEQ_SMALL1
 #undef FIVEEQ_SMALL_ARGS
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;

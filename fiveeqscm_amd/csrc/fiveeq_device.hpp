@@ -1040,7 +1040,7 @@ __device__ __forceinline__ float quad_bcast(const float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xf, 0xf, true));
 }
 
-template <typename T, int P0, int LPM>
+template <typename T, int P0, int LPM, bool STATS>
 __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void small_kernel(
     const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
     const int64_t n, const int64_t ld, const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R,
@@ -1054,9 +1054,11 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
     // per-64-member statistics records, batched over STAT_STEPS steps and folded by wave_stats_flush() exactly like the fused
     // kernel's (same tile layout, same order: the same record bits).  One lane per member: a tile per wave.  A quad per member:
     // the workgroup's four waves hold 16 members each = ONE record; they share a tile and wave 0 folds it between two barriers.
-    __shared__ T stat_tile[LPM == 1 ? FIVEEQ_SMALL_BLOCK / 64 : 1][STAT_STEPS * STAT_ROW];
+    // A compile-time variant (STATS): as a run-time test in the time loop it cost the statistics-free run 10 % (0.415 -> 0.456 us
+    // per step at 10k members).
+    __shared__ T stat_tile[!STATS ? 1 : (LPM == 1 ? FIVEEQ_SMALL_BLOCK / 64 : 1)][!STATS ? 1 : STAT_STEPS * STAT_ROW];
     const int64_t rec = LPM == 1 ? (int64_t)blockIdx.x * (FIVEEQ_SMALL_BLOCK / 64) + (threadIdx.x >> 6) : (int64_t)blockIdx.x;
-    const bool rec_live = stats != nullptr && rec < ((n + 63) >> 6);      // uniform over the wave (LPM = 1) / the workgroup (LPM = 4)
+    const bool rec_live = STATS && rec < ((n + 63) >> 6);                 // uniform over the wave (LPM = 1) / the workgroup (LPM = 4)
     const int n_valid = (int)min((int64_t)64, n - rec * 64);
     T* const tile = stat_tile[LPM == 1 ? threadIdx.x >> 6 : 0];
     int ks = 0;
@@ -1170,7 +1172,7 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
                     if (out_q != nullptr) out_q[(int64_t)row * ld] = sub == 0 ? Cg : Tn;
                 }
             }
-            if (rec_live) {
+            if constexpr (STATS) if (rec_live) {
                 if (LPM == 1 || sub == 0) tile[ks * STAT_ROW + (LPM == 1 ? (threadIdx.x & 63) : (threadIdx.x >> 2))] = Tn;
                 if (++ks == STAT_STEPS || tc + k + 1 == t_end) {
                     double* const out = stats + (rec * n_steps + (tc + k + 1 - ks)) * 4;
@@ -1205,7 +1207,7 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
 // three gases fit beside the state) and on a drive record held in registers and read one step ahead.  What a launch-bound
 // multi-gas ensemble gains over the fused kernel is the LDS round trips per step that nothing hides when a wave is alone on
 // its SIMD.  (A quad per gas would carry 4 members per wave: worth it below ~4k members only; not built.)
-template <typename T, int P0, int P1, int P2>
+template <typename T, int P0, int P1, int P2, bool STATS>
 __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void small_multi_kernel(
     const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
     const int64_t n, const int64_t ld, const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R,
@@ -1214,9 +1216,9 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
     using L = Layout<P0, P1, P2>;
     __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
     __shared__ int row_s[FIVEEQ_FUSED_CHUNK];
-    __shared__ T stat_tile[FIVEEQ_SMALL_BLOCK / 64][STAT_STEPS * STAT_ROW];          // statistics: as in small_kernel, one lane per member
+    __shared__ T stat_tile[!STATS ? 1 : FIVEEQ_SMALL_BLOCK / 64][!STATS ? 1 : STAT_STEPS * STAT_ROW];     // as in small_kernel, one lane per member
     const int64_t rec = (int64_t)blockIdx.x * (FIVEEQ_SMALL_BLOCK / 64) + (threadIdx.x >> 6);
-    const bool rec_live = stats != nullptr && rec < ((n + 63) >> 6);
+    const bool rec_live = STATS && rec < ((n + 63) >> 6);
     const int n_valid = (int)min((int64_t)64, n - rec * 64);
     T* const tile = stat_tile[threadIdx.x >> 6];
     int ks = 0;
@@ -1276,7 +1278,7 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
                 }
                 if (T_traj != nullptr) T_traj[(int64_t)row * ld + m] = Tn;
             }
-            if (rec_live) {
+            if constexpr (STATS) if (rec_live) {
                 tile[ks * STAT_ROW + (threadIdx.x & 63)] = Tn;
                 if (++ks == STAT_STEPS || tc + k + 1 == t_end) {
                     wave_stats_flush(tile, ks, n_valid, stats + (rec * n_steps + (tc + k + 1 - ks)) * 4, 4);

@@ -71,7 +71,7 @@ def test_fused_family_lines_price_their_own_kernel():
     d2 = _bench("--workload", "config2", "--mode", "auto", "--no-cpu-baseline", "--kernel-batches", "2")
     assert d2["config"]["mode"] == "auto" and d2["config"]["mode_resolved"] == "small" and d2["config"]["steps_per_launch"] == 750
     r2 = d2["roofline"]
-    assert r2["kernel"] == "fiveeq::small_kernel<double,4,4>" and r2["lanes_per_member"] == 4 and r2["waves"] == 625
+    assert r2["kernel"] == "fiveeq::small_kernel<double,4,4,false>" and r2["lanes_per_member"] == 4 and r2["waves"] == 625
     d3 = _bench("--workload", "config2", "--no-cpu-baseline", "--kernel-batches", "1", "--no-hbm-resident")
     assert d2["value"] > 3.0 * d3["value"]                      # ... against the launch-bound per-step form
     d4 = _bench("--workload", "config2", "--mode", "ksteps", "--no-cpu-baseline", "--kernel-batches", "2")

@@ -47,9 +47,9 @@ def main():
     kernels = {k for k, _ in acc}
     for k in sorted(kernels):
         # fused_kernel<V, P0, P1, P2, INV, BINS>: the plain forward form only
-        ms = re.match(r"fiveeq::small_kernel<(double|float), (\d), (\d)>", k)       # <T, P0, lanes per member>: single-gas layouts
+        ms = re.match(r"fiveeq::small_kernel<(double|float), (\d), (\d), false>", k)      # <T, P0, lanes per member, STATS>
         m = re.match(r"fiveeq::(step|fused)_kernel<(double|float2|float), (\d), (\d), (\d)((?:, (?:true|false))*)>", k)
-        mm_ = re.match(r"fiveeq::small_multi_kernel<(double|float), (\d), (\d), (\d)>", k)   # several gases: one lane per member
+        mm_ = re.match(r"fiveeq::small_multi_kernel<(double|float), (\d), (\d), (\d), false>", k)   # several gases: one lane per member
         if ms:
             m = re.match(r"(small) (\w+) (\d) (0) (0)()", f"small {ms.group(1)} {ms.group(2)} 0 0")
         if mm_:

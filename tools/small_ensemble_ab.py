@@ -16,13 +16,14 @@ from fiveeqscm_amd.engine import EnsembleEngine  # noqa: E402
 
 dtype = torch.float32 if "--f32" in sys.argv else torch.float64
 kind, G = ("multigas", 3) if "--multigas" in sys.argv else ("co2", 1)
+stats = "--stats" in sys.argv                       # per-64-member statistics records on, in every form
 sizes = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [10_000, 20_000, 40_000, 80_000, 160_000, 320_000]
 E = emissions.rcp_like_emissions(750, G)
-print(f"# {torch.cuda.get_device_name(0)}, dtype {dtype}, {kind}, 750 steps, trajectories stored; us per step (median of 7 passes)")
+print(f"# {torch.cuda.get_device_name(0)}, dtype {dtype}, {kind}, 750 steps, trajectories stored{', statistics on' if stats else ''}; us per step (median of 7 passes)")
 print(f"# {'members':>8} {'fused':>8} {'fused1':>8} {'ksteps':>8} {'small1':>8} {'small4':>8}   small4 member-steps/s   equal")
 for N in sizes:
     p = params.sample_ensemble_shard(params.default_params(kind), N, device="cuda:0", dtype=dtype)
-    eng = EnsembleEngine(p, N, E, dtype=dtype)
+    eng = EnsembleEngine(p, N, E, dtype=dtype, collect_stats=stats)
     eng.run(mode="per_step")
     torch.cuda.synchronize()
     ref = [eng.C.clone(), eng.T.clone(), eng.R.clone(), eng.S.clone()]
