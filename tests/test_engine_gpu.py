@@ -636,7 +636,8 @@ def test_all_compiled_layouts_match_oracle(gpu):
 def test_random_models_and_scenarios_match_oracle(gpu):
     """30 randomly drawn models (pool fractions and time-scales, feedback strengths, forcing
     coefficients, box time-scales, dt) x random emission series with spikes and negative spells,
-    every compiled gas count: per-step and fused paths against the NumPy oracle at 1e-10."""
+    every compiled gas count: per-step, fused and small-ensemble paths against the NumPy oracle at 1e-10, and bit-identical
+    among themselves (random forcing coefficients: the log, linear and square-root terms all on, or some of them exactly 0)."""
     rng = np.random.default_rng(2026)
     worst = 0.0
     for case in range(30):
@@ -658,6 +659,7 @@ def test_random_models_and_scenarios_match_oracle(gpu):
                 "emis2conc": rng.uniform(0.1, 0.6, G), "f": rng.uniform(0, 1, (G, 3)) * np.array([5.0, 0.01, 0.1]),
                 "iirf_max": float(rng.uniform(60, 110)), "d": np.array([rng.uniform(100, 400), rng.uniform(1, 9)]),
                 "q": rng.uniform(0.1, 0.6, 2)}
+        base["f"][rng.uniform(size=(G, 3)) < 0.25] = 0.0              # terms switched off exactly: the kernels skip them
         p = prm.sample_ensemble(base, N, seed=case)
         E = rng.normal(0, 1, (n_steps, G)).cumsum(0) * rng.uniform(0.1, 3.0, G) + rng.uniform(0, 8, G)
         E[rng.integers(0, n_steps, 3)] *= 6.0                          # spikes
@@ -665,10 +667,14 @@ def test_random_models_and_scenarios_match_oracle(gpu):
         want = npo.run(E, p, N, F_ext=F_ext, dt=dt)
         if not (np.all(np.isfinite(want["C"])) and np.all(np.isfinite(want["T"]))):
             continue                                                   # a draw the model itself cannot digest
-        for mode in ("per_step", "fused"):
-            eng = _engine(p, N, E, F_ext=F_ext, dt=dt)
+        first = None
+        for mode, lanes in (("per_step", "auto"), ("fused", "auto"), ("small", 1)) + ((("small", 4),) if pools == [4] else ()):
+            eng = _engine(p, N, E, F_ext=F_ext, dt=dt, small_lanes=lanes)
             eng.run(mode=mode)
             torch.cuda.synchronize()
+            if first is None:
+                first = (eng.C.clone(), eng.T.clone())
+            assert torch.equal(eng.C, first[0]) and torch.equal(eng.T, first[1]), (case, mode, lanes, pools)    # one arithmetic
             scale = np.maximum(np.abs(want["C"]), np.abs(want["C"] - np.asarray(base["PI_conc"])[None, :, None]).max())
             errC = np.abs(eng.C.cpu().numpy() - want["C"]) / (RTOL * scale + ATOL)
             errT = np.abs(eng.T.cpu().numpy() - want["T"]) / (RTOL * np.maximum(np.abs(want["T"]), np.abs(want["T"]).max())
