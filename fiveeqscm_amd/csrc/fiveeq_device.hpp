@@ -1153,8 +1153,15 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
             const T Cg = kg.C0 + sumN;
             const bool pos = Cg > T(0);
             T Fg = kg.f2 * (Cg - kg.C0);
-            if (kg.f1 != T(0)) Fg = pos ? fe_fma(kg.f1, fe_log(pos ? Cg * kg.inv_C0 : T(1)), Fg) : Fg;
-            if (kg.f3 != T(0)) Fg = fe_fma(kg.f3, (pos ? fe_sqrt(pos ? Cg : T(1)) : T(0)) - kg.sqrtC0, Fg);
+            if (kg.f1 != T(0)) {                                         // gas_step()'s values, selected instead of branched around:
+                const T lg = fe_log(pos ? Cg * kg.inv_C0 : T(1));        // straight-line code schedules better in a lone wave (-1...-3 %)
+                const T with_log = fe_fma(kg.f1, lg, Fg);
+                Fg = pos ? with_log : Fg;
+            }
+            if (kg.f3 != T(0)) {
+                const T sq = fe_sqrt(pos ? Cg : T(1));
+                Fg = fe_fma(kg.f3, (pos ? sq : T(0)) - kg.sqrtC0, Fg);
+            }
             T F = Fx;
             F += Fg;
 #pragma unroll

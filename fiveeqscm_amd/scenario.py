@@ -99,3 +99,43 @@ def write_emissions_csv(path, years, emissions, gases=("CO2", "CH4", "N2O"), tit
             for g, v in zip(gases, row):
                 cells += [repr(float(v)), "0.0"] if g == "CO2" else [repr(float(v))]
             w.writerow([repr(float(y)) if y != int(y) else int(y)] + cells)
+
+
+def write_summary_csv(path, years, summary, percentiles=(5.0, 50.0, 95.0), quantity="T", unit="K"):
+    """The output side: the end-of-run summary of an ensemble (the dict `distributed.gather_summary` /
+    `EnsembleEngine.gather_summary` return on the root rank: count, mean, var, min, max [K] and percentiles [K, P]) as one CSV
+    row per output year — YEAR, COUNT, MEAN, STD, MIN, P05, P50, P95, MAX (columns named after `percentiles`) — with repr-exact
+    floats, so that `read_summary_csv` returns the numbers bit for bit."""
+    years = np.asarray(years, dtype=np.float64).reshape(-1)
+    cols = {k: np.asarray(summary[k], dtype=np.float64).reshape(-1) for k in ("count", "mean", "var", "min", "max")}
+    if summary.get("percentiles") is None:
+        raise ValueError("summary holds no percentiles (they exist on the root rank of the exchange only)")
+    pct = np.asarray(summary["percentiles"], dtype=np.float64).reshape(years.size, -1)
+    if pct.shape[1] != len(percentiles) or any(v.size != years.size for v in cols.values()):
+        raise ValueError(f"summary of {cols['mean'].size} rows x {pct.shape[1]} percentiles does not match {years.size} years x "
+                         f"{len(percentiles)} percentiles")
+    names = ["P%s" % (("%02d" % p) if float(p).is_integer() else repr(float(p))) for p in percentiles]
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow([f"fiveeqscm_amd ensemble summary of {quantity} ({unit})"])
+        w.writerow(["YEAR", "COUNT", "MEAN", "STD", "MIN"] + names + ["MAX"])
+        for k, y in enumerate(years):
+            w.writerow([int(y) if y == int(y) else repr(float(y)), int(cols["count"][k]), repr(float(cols["mean"][k])),
+                        repr(float(np.sqrt(cols["var"][k]))), repr(float(cols["min"][k]))]
+                       + [repr(float(v)) for v in pct[k]] + [repr(float(cols["max"][k]))])
+
+
+def read_summary_csv(path):
+    """(years [K], dict of columns) of a file written by `write_summary_csv`; the percentile columns come back as
+    'percentiles' [K, P] with their levels in 'levels'."""
+    with open(path, newline="") as fh:
+        rows = [row for row in csv.reader(fh) if row]
+    header = next((r for r in rows if r and r[0] == "YEAR"), None)
+    if header is None:
+        raise ValueError(f"{path}: no YEAR header row")
+    data = np.array([[float(c) for c in r] for r in rows[rows.index(header) + 1:]], dtype=np.float64).reshape(-1, len(header))
+    out = {name.lower(): data[:, i] for i, name in enumerate(header) if not name.startswith("P") and name != "YEAR"}
+    pcols = [i for i, name in enumerate(header) if name.startswith("P")]
+    out["levels"] = [float(header[i][1:]) for i in pcols]
+    out["percentiles"] = data[:, pcols]
+    return data[:, 0], out

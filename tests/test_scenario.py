@@ -68,14 +68,23 @@ def test_a_csv_scenario_through_the_engine(tmp_path):
     write_emissions_csv(path, 1765 + np.arange(750), E)
     years, E_file = read_emissions_csv(path)
     assert years[0] == 1765 and years[-1] == 2514
-    a = EnsembleEngine(p, N, E, device="cuda:0", output_steps=list(range(0, 750, 50)) + [749])
-    b = EnsembleEngine(p, N, E_file, device="cuda:0", output_steps=list(range(0, 750, 50)) + [749])
+    stored = sorted(set(list(range(0, 750, 50)) + [249, 499, 749]))
+    a = EnsembleEngine(p, N, E, device="cuda:0", output_steps=stored)
+    b = EnsembleEngine(p, N, E_file, device="cuda:0", output_steps=stored)
     a.run(mode="per_step")
     b.run(mode="fused")
     torch.cuda.synchronize()
     for name in ("C", "T", "R", "S"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert torch.equal(a.drive, b.drive)
+    # ... and out again: the end-of-run summary of the run as a CSV, bit for bit
+    from fiveeqscm_amd.scenario import read_summary_csv, write_summary_csv
+    summ = b.gather_summary([249, 499, 749])
+    write_summary_csv(tmp_path / "summary.csv", years[[249, 499, 749]], {k: (v.numpy() if v is not None else None) for k, v in summ.items()})
+    y3, back = read_summary_csv(tmp_path / "summary.csv")
+    assert y3.tolist() == [2014.0, 2264.0, 2514.0] and np.array_equal(back["percentiles"], summ["percentiles"].numpy())
+    rows = [stored.index(t) for t in (249, 499, 749)]
+    assert np.array_equal(back["percentiles"], np.percentile(a.T[rows].cpu().numpy(), (5.0, 50.0, 95.0), axis=1).T)
     a.close(), b.close()
     _, E5 = read_emissions_csv(os.path.join(HERE, "golden", "rcp_layout_sample.csv"))
     n = 777
@@ -89,3 +98,23 @@ def test_a_csv_scenario_through_the_engine(tmp_path):
             got = getattr(eng, name).cpu().numpy()
             assert np.all(np.abs(got - want[name]) <= 1e-10 * np.abs(want[name]) + 1e-13), (mode, name)
         eng.close()
+
+
+def test_summary_csv_roundtrip(tmp_path):
+    """The output side of scenario I/O: an end-of-run summary (moments + exact percentiles per output year) written as CSV and
+    read back bit for bit; a summary without percentiles (a non-root rank's) is refused."""
+    from fiveeqscm_amd.scenario import read_summary_csv, write_summary_csv
+    rng = np.random.default_rng(4)
+    K = 3
+    summ = {"count": np.full(K, 1e6), "mean": rng.normal(2, 1, K), "var": rng.uniform(0.1, 1, K), "min": rng.normal(0, 1, K),
+            "max": rng.normal(5, 1, K), "percentiles": np.sort(rng.normal(2, 1, (K, 4)), axis=1)}
+    path = tmp_path / "summary.csv"
+    write_summary_csv(path, [2014, 2264, 2514], summ, percentiles=(5, 50, 95, 99.5))
+    years, back = read_summary_csv(path)
+    assert years.tolist() == [2014.0, 2264.0, 2514.0] and back["levels"] == [5.0, 50.0, 95.0, 99.5]
+    assert np.array_equal(back["percentiles"], summ["percentiles"]) and np.array_equal(back["mean"], summ["mean"])
+    assert np.array_equal(back["std"], np.sqrt(summ["var"])) and np.array_equal(back["min"], summ["min"]) and back["count"].tolist() == [1e6] * 3
+    with pytest.raises(ValueError, match="root rank"):
+        write_summary_csv(path, [1, 2, 3], dict(summ, percentiles=None))
+    with pytest.raises(ValueError, match="does not match"):
+        write_summary_csv(path, [1, 2], summ, percentiles=(5, 50, 95, 99.5))
