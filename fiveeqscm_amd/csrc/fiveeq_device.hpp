@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
     const int64_t rec = LPM == 1 ? (int64_t)blockIdx.x * (FIVEEQ_SMALL_BLOCK / 64) + (threadIdx.x >> 6) : (int64_t)blockIdx.x;
     const bool rec_live = STATS && rec < ((n + 63) >> 6);                 // uniform over the wave (LPM = 1) / the workgroup (LPM = 4)
     const int n_valid = (int)min((int64_t)64, n - rec * 64);
-    T* const tile = stat_tile[LPM == 1 ? threadIdx.x >> 6 : 0];
+    T* const tile = STATS ? stat_tile[LPM == 1 ? threadIdx.x >> 6 : 0] : nullptr;
     int ks = 0;
     const int lane = threadIdx.x;
     const int sub = lane % LPM;                                          // the pool this lane carries (LPM = 4)
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
     const int64_t rec = (int64_t)blockIdx.x * (FIVEEQ_SMALL_BLOCK / 64) + (threadIdx.x >> 6);
     const bool rec_live = STATS && rec < ((n + 63) >> 6);
     const int n_valid = (int)min((int64_t)64, n - rec * 64);
-    T* const tile = stat_tile[threadIdx.x >> 6];
+    T* const tile = STATS ? stat_tile[threadIdx.x >> 6] : nullptr;
     int ks = 0;
     // fp64: the model, word by word, into VECTOR registers.  Left to itself the compiler keeps the ~45 constants of three
     // gases in scalar registers, runs out of them (two each) and spills — 83 v_readlane per step, 1.25 us per step instead of
