@@ -38,5 +38,5 @@ python3 bench.py --no-cpu-baseline --workload config5 --dtype f32 --mode fused -
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-hbm-resident > $OUT/bench_config3_under_rocprof.json 2> $OUT/trace.err
 for k in kernel_stats domain_stats; do src=$(ls -t $OUT/trace/*/*_$k.csv 2>/dev/null | head -1); [ -n "$src" ] && cp "$src" $OUT/${k}_bench_config3.csv; done
-rm -rf $OUT/pmc_sq*_fused32 $OUT/pmc_sq*_step32 $OUT/pmc_sq*_small $OUT/trace
+rm -rf $OUT/pmc_sq*_fused32 $OUT/pmc_sq*_step32 $OUT/pmc_sq*_small* $OUT/trace
 ls $OUT
