@@ -44,14 +44,15 @@ PER_STEP_BLOCK = 25                  # steps enqueued per part before switching 
 FUSED_SPAN_STEPS = 128               # mode='fused': steps per launch for ensembles of few rounds of waves (see fused_span)
 FUSED_SPAN_MAX_ROUNDS = 8.0          # ... up to this many rounds of 4 waves per SIMD
 FUSED_SPAN_MIN_ROUNDS = 0.25         # ... and from this many on
-# mode='auto' takes the small-ensemble kernel (include/fiveeq.h, fiveeq_run_small_*): for a lone 4-pool gas one member per
-# QUAD of lanes while the quads' waves get a SIMD each (one 256-thread workgroup per CU: 64 members per CU, 16384 on an
-# MI355X; past that two waves share a SIMD and the unspread form is ahead), one member per lane up to this many members
-# (fp64 CO2-only, us per step: 0.42 / 0.54 / 0.73 quad / one lane / fused kernel at 10k members, 0.92 / 1.04 one lane /
-# fused at 100k, a tie at 130k; three gases: 0.94 / 1.38 at 10k, 1.65 / 1.93 at 100k, a tie at 200k:
-# profiles/r05/small_ensemble_ab.txt, small_ensemble_multigas_ab.txt)
-SMALL_ONE_LANE_MAX_MEMBERS = 100_000
+# mode='auto' on a LAUNCH-BOUND ensemble (auto_k_steps() > 1) takes the small-ensemble kernel (include/fiveeq.h,
+# fiveeq_run_small_*): for a lone 4-pool gas one member per QUAD of lanes while the quads' waves get a SIMD each (one
+# 256-thread workgroup per CU: 64 members per CU, 16384 on an MI355X; past that two waves share a SIMD and the unspread form
+# is ahead), else one member per lane (fp64 CO2-only, us per step: 0.41 / 0.54 / 0.73 quad / one lane / fused kernel at 10k
+# members, 0.89 / 1.09 one lane / fused at 110k, 1.74 / 1.90 at 250k; three gases: 0.94 / 1.38 at 10k, 1.66 / 1.98 at 110k,
+# 2.40 / 2.65 at 150k: profiles/r05/small_ensemble_ab.txt, small_ensemble_multigas_ab.txt, auto_window_sweep.txt)
 SMALL_QUAD_MEMBERS_PER_CU = 64
+KSTEPS_LAUNCH_BOUND = 128            # steps per launch of the K-step form on a launch-bound ensemble (2 / 8 / 32 / 128 steps per
+                                     # launch at 110k three-gas members: 4.42 / 2.70 / 2.13 / 1.97 us per step; one launch: 1.98)
 
 
 def _rows(x, K, N, name):
@@ -244,14 +245,12 @@ class EnsembleEngine(CheckpointMixin):
         return min(FUSED_SPAN_STEPS, n_steps) if FUSED_SPAN_MIN_ROUNDS <= rounds <= FUSED_SPAN_MAX_ROUNDS else n_steps
 
     def auto_k_steps(self):
-        """Steps per launch for mode='auto': 1 (the per-step kernel) while one step's HBM traffic hides the
-        dependent-launch boundary, otherwise the K that brings a launch's traffic time to ~3 boundaries
-        (capped at 32: a launch costs ~2.6 us beside ~0.75 us per step of a 10k-member ensemble): small ensembles are
-        launch-bound, not bandwidth-bound."""
+        """Steps per launch of the per-step family: 1 (the per-step kernel, the north-star form) while one step's HBM traffic
+        hides the dependent-launch boundary (at least three boundaries' worth: ~160k three-gas fp64 members), otherwise —
+        the ensemble is launch-bound, not bandwidth-bound — KSTEPS_LAUNCH_BOUND: state and parameters cross HBM once per
+        launch, so nothing is gained by a shorter span (round 4 scaled K with the ensemble and ran 110k members at K = 2)."""
         t_step = self.n_members * self.bytes_per_member_step("per_step") / HBM_STREAM_BYTES_PER_S
-        if t_step >= 3.0 * LAUNCH_BOUNDARY_S:
-            return 1
-        return int(min(32, max(2, round(3.0 * LAUNCH_BOUNDARY_S / max(t_step, 1e-9)))))
+        return 1 if t_step >= 3.0 * LAUNCH_BOUNDARY_S else min(KSTEPS_LAUNCH_BOUND, self.n_steps)
 
     def small_form(self):
         """Lanes per member mode='small' would run with now (4 or 1); 0 = the small-ensemble kernel does not apply: a run that
@@ -264,19 +263,20 @@ class EnsembleEngine(CheckpointMixin):
         return 4 if self.small_widest == 4 and self.n_members <= SMALL_QUAD_MEMBERS_PER_CU * cus else 1
 
     def resolve_mode(self, mode, k_steps=None):
-        """(mode, k_steps) run() uses for a request: 'auto' resolved, everything else as given.  'auto' is the small-ensemble
-        kernel where it applies and wins (small_form(), SMALL_ONE_LANE_MAX_MEMBERS), else 'per_step' while a step's HBM
-        traffic hides the launch boundary, else the time-fused family: 'ksteps' — or, on an engine with hist=, 'fused' (the
-        streamed histogram pipeline), the fastest form that fills T_hist on a launch-bound ensemble
-        (profiles/r04/auto_hist_table.txt)."""
+        """(mode, k_steps) run() uses for a request: 'auto' resolved, everything else as given.  'auto' is 'per_step' (the
+        north-star form) while a step's HBM traffic hides the launch boundary; a launch-bound ensemble takes the small-ensemble
+        kernel (small_form()) — or, with hist=, 'fused' (the streamed histogram pipeline, the fastest form that fills T_hist
+        there: profiles/r04/auto_hist_table.txt); an explicit k_steps, or a run the small kernel does not serve, 'ksteps'."""
         if mode != "auto":
             return mode, k_steps
-        if k_steps is None and self.small_form() and self.n_members <= SMALL_ONE_LANE_MAX_MEMBERS:
-            return "small", None
-        k_steps = self.auto_k_steps() if k_steps is None else int(k_steps)
-        if k_steps <= 1:
+        k = self.auto_k_steps() if k_steps is None else int(k_steps)
+        if k <= 1:
             return "per_step", None
-        return ("fused", None) if self.T_hist is not None else ("ksteps", k_steps)
+        if self.T_hist is not None:
+            return "fused", None
+        if k_steps is None and self.small_form():
+            return "small", None
+        return "ksteps", k
 
     # -- state -------------------------------------------------------------------------
     def reset_state(self):

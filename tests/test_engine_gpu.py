@@ -377,13 +377,13 @@ def test_small_ensemble_kernel_ragged_sizes_layouts_and_resume(gpu):
 
 
 def test_auto_takes_the_small_ensemble_kernel_where_the_measured_table_says(gpu):
-    """profiles/r05/small_ensemble_ab.txt: the quad form while its waves get a SIMD each (64 members per CU), the one-lane form
-    up to 100k members, then the K-step / per-step family; never with statistics, histograms, several gases or the inverse
-    form."""
+    """profiles/r05/small_ensemble_ab.txt, auto_window_sweep.txt: a launch-bound ensemble takes the small-ensemble kernel — the
+    quad form while its waves get a SIMD each (64 members per CU), else one member per lane — and an ensemble whose step hides
+    the launch boundary the per-step kernel; with hist= the streamed pipeline; never the inverse form."""
     E = emi.rcp_like_emissions(30, 1)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     for N, mode, lanes in ((10_000, "small", 4), (64 * cus, "small", 4), (64 * cus + 1, "small", 1), (100_000, "small", 1),
-                           (100_001, "ksteps", 1), (4_000_000, "per_step", 1)):
+                           (250_000, "small", 1), (300_000, "per_step", 1), (4_000_000, "per_step", 1)):
         p = prm.sample_ensemble_shard(prm.default_params("co2"), N, device="cuda:0")
         eng = _engine(p, N, E, store_trajectory=N < 1_000_000)
         assert eng.resolve_mode("auto")[0] == mode and (mode != "small" or eng.small_form() == lanes), (N, mode, lanes)
@@ -392,6 +392,8 @@ def test_auto_takes_the_small_ensemble_kernel_where_the_measured_table_says(gpu)
     assert _engine(p, 5000, E, collect_stats=True).resolve_mode("auto")[0] == "small"                # statistics ride along
     assert _engine(p, 5000, E, hist=(-1.0, 5.0, 64)).resolve_mode("auto")[0] == "fused"
     assert _engine(p, 5000, E).resolve_mode("auto", 7) == ("ksteps", 7)               # an explicit K is taken as given
+    assert _engine(p, 5000, E).auto_k_steps() == 30                                    # K-step form, launch-bound: the whole span
+    assert _engine(p, 5000, emi.rcp_like_emissions(750, 1)).auto_k_steps() == 128
     pm = prm.sample_ensemble(prm.default_params("multigas"), 5000)
     em = _engine(pm, 5000, emi.rcp_like_emissions(30, 3))
     assert em.small_widest == 1 and em.resolve_mode("auto")[0] == "small" and em.small_form() == 1     # three gases: one lane
@@ -1486,7 +1488,7 @@ def test_calibrate_measures_the_box_dependent_constants(gpu):
         assert eng_mod.LAUNCH_BOUNDARY_S != before[1] or eng_mod.HBM_STREAM_BYTES_PER_S != before[0]
         p = prm.sample_ensemble(prm.default_params("co2"), 1000)
         eng = _engine(p, 1000, emi.rcp_like_emissions(10, 1))
-        assert 2 <= eng.auto_k_steps() <= 32                       # a 1000-member ensemble stays launch-bound on any box
+        assert 2 <= eng.auto_k_steps() <= 128                      # a 1000-member ensemble stays launch-bound on any box
         eng.close()
     finally:
         eng_mod.HBM_STREAM_BYTES_PER_S, eng_mod.LAUNCH_BOUNDARY_S = before
