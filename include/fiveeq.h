@@ -209,8 +209,10 @@ int fiveeq_run_ksteps_f32(const fiveeq_model *model, int64_t n_members, int64_t 
  * fiveeq_run_fused_*, 16 members per wave.  lanes_per_member: 4, 1 (one member per lane with the model in registers: every
  * compiled layout, several gases included) or 0 = the widest form the layout has (fiveeq_small_lanes).  One launch for the
  * whole span; C_traj, T_traj, the row map and T_stats as in the other entry points (the statistics records are the fused
- * kernel's bit for bit).  Same arithmetic operation for operation: bit-identical results to the per-step path.  Ahead of the fused kernel up to ~100k members (10k members, us per step: CO2-only fp64 0.42 against 0.73,
- * three gases fp64 0.94 against 1.38, fp32 0.51 against 1.16). */
+ * kernel's bit for bit).  Same arithmetic operation for operation: bit-identical results to the per-step path.
+ * Ahead of the fused kernel while the ensemble is launch-bound — about 64 members per CU for the quad form, a few hundred
+ * thousand members for the one-lane form (10k members, us per step: CO2-only fp64 0.42 against 0.73, three gases fp64 0.94
+ * against 1.38, fp32 0.51 against 1.16). */
 int fiveeq_run_small_f64(const fiveeq_model *model, int64_t n_members, int64_t ld,
                          const double *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
                          const double *r, const double *q, double *R, double *S,
