@@ -608,23 +608,27 @@ class EnsembleEngine(CheckpointMixin):
         from .distributed import moments_from_sums
         return moments_from_sums(self.stats_sums(t_begin, t_end))
 
-    def gather_summary(self, steps, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats=None):
-        """End-of-run summary of T at the stored `steps` over ALL members of all ranks (collective over `group`; see
-        distributed.gather_summary): merged moments on every rank, exact percentiles on rank `dst`.  With
-        collect_stats the moments come from the records the kernels wrote while stepping — the summary then reads the
-        rows twice (histogram, selection) instead of three times."""
+    def gather_summary(self, steps, percentiles=(5.0, 50.0, 95.0), dst=0, group=None, stats=None, gas=None):
+        """End-of-run summary of T — or, with `gas` = a gas index, of that gas's concentration C — at the stored `steps` over
+        ALL members of all ranks (collective over `group`; see distributed.gather_summary): merged moments on every rank,
+        exact percentiles on rank `dst`.  With collect_stats the moments of T come from the records the kernels wrote while
+        stepping — the summary then reads the rows twice (histogram, selection) instead of three times."""
         from .distributed import gather_summary
-        if self.T is None:
-            raise RuntimeError("no stored T rows to summarise")
+        stored = self.T if gas is None else self.C
+        if stored is None or self.concentration_driven and gas is not None:
+            raise RuntimeError(f"no stored {'T' if gas is None else 'C'} rows to summarise")
+        if gas is not None and not 0 <= int(gas) < self.n_gas:
+            raise ValueError(f"gas {gas}: the parameter set has gases 0..{self.n_gas - 1}")
         if self._ps_unjoined:
             self.join()
         row_of = {int(t): r for r, t in enumerate(self.out_steps)}
         missing = [int(t) for t in steps if int(t) not in row_of]
         if missing:
             raise ValueError(f"steps {missing} are not stored (out_steps)")
-        rows = self.T[[row_of[int(t)] for t in steps]]
+        picked = [row_of[int(t)] for t in steps]
+        rows = self.T[picked] if gas is None else self.C[picked, int(gas)]
         sums = None
-        if self.collect_stats and all(self._stats_have[int(t)] for t in steps):       # else: the moments pass over the rows
+        if gas is None and self.collect_stats and all(self._stats_have[int(t)] for t in steps):   # else: the moments pass over the rows
             sums = torch.cat([self.stats_sums(int(t), int(t) + 1) for t in steps])[:, 1:5].contiguous()
         return gather_summary(rows, percentiles, dst=dst, group=group, stats=stats, local_sums=sums)
 

@@ -1289,6 +1289,40 @@ def test_full_size_config5_shard_fp32_sparse_outputs(gpu):
     assert st["count"][0].item() == float(N)
 
 
+def test_whole_config5_ensemble_on_one_gpu(gpu):
+    """BASELINE configs[4] WHOLE — 100,000,000 distinct fp32 Latin-hypercube members — on ONE MI355X (7.6 GB of state and
+    parameters of 288 GB; three stored years; the per-wave statistics records alone are 37.5 GB, their offsets pass 2^32):
+    the maximum size the configs name, with every index past 32 bits somewhere.  Size-independent checks: a strided sample
+    of 4096 members against the fp64 oracle run on the same (fp32-rounded) parameters; the per-step path for the first
+    steps bit for bit against the time-fused launch; the on-device moments against the stored rows, every member counted."""
+    N, n_steps, years = 100_000_000, 750, [9, 249, 749]
+    if torch.cuda.mem_get_info()[0] < 120 << 30:
+        pytest.skip("needs ~100 GB of free HBM")
+    pd = prm.sample_ensemble_shard(prm.default_params("multigas"), N, device=gpu, dtype=torch.float32)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    eng = _engine(pd, N, E, dtype=torch.float32, output_steps=years, collect_stats=True)
+    eng.run(mode="fused")
+    torch.cuda.synchronize()
+    idx = torch.arange(4096, device=gpu) * (N // 4096) + 17
+    sample = dict(pd)
+    for k in ("r0", "rC", "rT", "q"):
+        sample[k] = pd[k][:, idx].double().cpu().numpy()
+    want = c_oracle.run(E, sample, 4096, n_threads=8)
+    _close(eng.T[:, idx].double(), want["T"][years], what="T sample fp32", **FP32_T)
+    _close(eng.C[:, :, idx].double(), want["C"][years], what="C sample fp32", **FP32_C)
+    st = eng.stats()
+    assert st["count"].tolist() == [float(N)] * n_steps
+    for row, t in enumerate(years):
+        x = eng.T[row].double()
+        assert abs(st["mean"][t].item() - x.mean().item()) <= 1e-11 * abs(x.mean().item())
+        assert st["min"][t].item() == x.min().item() and st["max"][t].item() == x.max().item()
+    T9, C9 = eng.T[0].clone(), eng.C[0].clone()
+    eng.reset_state()
+    eng.run(0, 10, mode="per_step")
+    torch.cuda.synchronize()
+    assert torch.equal(eng.T[0], T9) and torch.equal(eng.C[0], C9)
+
+
 def test_full_size_config3_direct_parity_of_final_state(gpu):
     """BASELINE configs[2] at full size with 1,000,000 DISTINCT Latin-hypercube members (no tiling): the
     final pools and thermal boxes after 750 steps against the plain-C oracle run on all usable host threads

@@ -166,6 +166,31 @@ def test_engine_summary_takes_its_moments_from_the_kernel_records():
     assert torch.equal(sc["percentiles"], sb["percentiles"]) and torch.allclose(sc["mean"], sb["mean"], rtol=1e-13)
 
 
+def test_engine_summary_of_a_gas_concentration():
+    """"summary statistics of T (and optionally C)": gas= summarises that gas's stored C rows through the
+    same four passes — np.percentile bit for bit, moments to rounding; T's summary is unchanged beside it."""
+    from fiveeqscm_amd import emissions, params
+    from fiveeqscm_amd.engine import EnsembleEngine
+    N, steps = 30_011, [10, 59]
+    p = params.sample_ensemble_shard(params.default_params("multigas"), N, device="cuda:0")
+    E = emissions.rcp_like_emissions(750, 3)[200:260]
+    eng = EnsembleEngine(p, N, E, device="cuda:0", output_steps=steps, collect_stats=True)
+    eng.run(mode="fused")
+    C = eng.C.cpu().numpy()
+    for g in range(3):
+        s = eng.gather_summary(steps, percentiles=PCT, gas=g)
+        assert np.array_equal(s["percentiles"].cpu().numpy(), np.percentile(C[:, g], PCT, axis=1).T), g
+        np.testing.assert_allclose(s["mean"].cpu().numpy(), C[:, g].mean(1), rtol=1e-13)
+        assert np.array_equal(s["min"].cpu().numpy(), C[:, g].min(1)) and np.array_equal(s["max"].cpu().numpy(), C[:, g].max(1))
+    assert np.array_equal(eng.gather_summary(steps, percentiles=PCT)["percentiles"].cpu().numpy(),
+                          np.percentile(eng.T.cpu().numpy(), PCT, axis=1).T)
+    with pytest.raises(ValueError, match="gases 0..2"):
+        eng.gather_summary(steps, gas=3)
+    no_c = EnsembleEngine(p, N, E, device="cuda:0", output_steps=steps, store_concentrations=False)
+    with pytest.raises(RuntimeError, match="no stored C rows"):
+        no_c.gather_summary(steps, gas=0)
+
+
 def test_hip_passes_against_their_numpy_restatement():
     """oracle/summary_passes.py restates the four passes in NumPy behind the C ABI's signatures (it stands in for the library
     in the CPU tests of the multi-rank exchange).  Here the two meet on the same rows: moments, histogram counts, candidate
