@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FIVEEQ_LIB_PATH selects another build of the same library (e.g. the host-sanitizer build of tools/sanitize_host.sh)
 LIB_PATH = os.environ.get("FIVEEQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_GAS = 3
 MAX_POOLS = 4
 N_BOX = 2
@@ -97,6 +97,8 @@ SIGNATURES = {
     "fiveeq_run_small_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
     "fiveeq_small_lanes": (_i32, [_i32, ctypes.POINTER(_i32)]),
     "fiveeq_set_f32_packing": (ctypes.c_int, [ctypes.c_int]),
+    "fiveeq_set_row_policy": (ctypes.c_int, [_i32]),
+    "fiveeq_rows_streamed": (ctypes.c_int, [_i32, ctypes.POINTER(_i32), _i64, _i64, _i32]),
     "fiveeq_lhs_rows_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p, _p]),
     "fiveeq_lhs_rows_host_f64": (ctypes.c_int, [ctypes.c_uint64, _i64, _i64, _i64, _i32, _i32, _i64, _p]),
     "fiveeq_plan_launch": (ctypes.c_int, [_p, _p]),
@@ -115,6 +117,8 @@ SIGNATURES = {
     "fiveeq_select_pick_f32": (ctypes.c_int, [_i32, _i32, _i64, _p, _p, _i32, _p, _p, _p]),
     "fiveeq_stream_copy_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
     "fiveeq_stream_copy_wide_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
+    "fiveeq_stream_copy_nt_f64": (ctypes.c_int, [_i64, _p, _p, _p]),
+    "fiveeq_busy": (ctypes.c_int, [_i64, _p, _p]),
     "fiveeq_math_probe_f64": (ctypes.c_int, [_i32, _i64, _p, _p, _p]),
     "fiveeq_math_probe_f32": (ctypes.c_int, [_i32, _i64, _p, _p, _p]),
 }

@@ -150,6 +150,7 @@ struct RunArgs {
     int n_steps;
     double* stats;
     int packing;                 // the fp32 packing switch as this call found it
+    bool stream_rows;            // the per-step launches of this call take the STREAMED (non-temporal) row form
 };
 
 // the bin-index ring of the streamed histograms (fused_kernel<..., BINS = true>)
@@ -168,6 +169,24 @@ struct BinRing {
 // Process-wide and changeable at any time from any thread: a relaxed atomic, read ONCE per C-ABI call (make_args), so that
 // every launch of one call takes the same kernel shape.
 std::atomic<int> g_f32_packing{1};
+
+// ---- cache policy of the per-step kernel's state and parameter rows (fiveeq_device.hpp, step_kernel<..., NT>) --------------
+// STREAMED (non-temporal) pays exactly when the rows of this launch cannot be in the Infinity Cache at the next step:
+//   * the launch's own rows fill it: n members x (SP + 2 + 3G + 2) words >= the cache — false for the chunks of a chunk-major
+//     schedule (the engine sizes them to fit), true for an unchunked multi-million-member launch; and
+//   * the ensemble they are a part of (row length ld: the halves of a two-stream split share the cache) is at least twice
+//     the cache — between one and two cache sizes the default policy still hits often enough to win (2M fp64 members, 304 MB:
+//     +13 % streamed; 4M: -9 %; profiles/r05/step_row_policy_ab.txt).
+// fiveeq_set_row_policy overrides the rule process-wide (A/B measurements, the bit-identity tests); like the packing switch
+// it is a relaxed atomic read ONCE per C-ABI call.
+constexpr int64_t INFINITY_CACHE_BYTES = (int64_t)256 << 20;       // MI355X (MI355X_MICROARCH.md)
+std::atomic<int> g_row_policy{FIVEEQ_ROWS_AUTO};
+
+bool rows_streamed(int policy, int n_gas, int sum_pools, int64_t n, int64_t ld, int word) {
+    if (policy != FIVEEQ_ROWS_AUTO) return policy == FIVEEQ_ROWS_STREAMED;
+    const int64_t per_member = (int64_t)word * (sum_pools + 2 + 3 * n_gas + 2);
+    return n * per_member >= INFINITY_CACHE_BYTES && ld * per_member >= 2 * INFINITY_CACHE_BYTES;
+}
 
 template <typename T>
 struct LaneOf {
@@ -194,19 +213,24 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st, const BinRing& br = 
     if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
     const dim3 grid((unsigned)blocks), block(FIVEEQ_STEP_BLOCK);
     switch (a.code) {
+#define FIVEEQ_STEP_LAUNCH(V, p0, p1, p2, NT)                                                                                  \
+    hipLaunchKernelGGL((step_kernel<V, p0, p1, p2, BINS, NT>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, a.ld, a.r, \
+                       a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, br.ring, br.ring_rows, br.lo, br.inv_w, br.n_bins)
 #define X(p0, p1, p2)                                                                             \
     case (p0) * 100 + (p1) * 10 + (p2):                                                           \
-        if (packed)                                                                               \
-            hipLaunchKernelGGL((step_kernel<P, p0, p1, p2, BINS>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
-                               a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, br.ring, br.ring_rows,     \
-                               br.lo, br.inv_w, br.n_bins);                                       \
-        else                                                                                      \
-            hipLaunchKernelGGL((step_kernel<T, p0, p1, p2, BINS>), grid, block, 0, st, a.km, a.drive, a.n_steps, t, a.n, \
-                               a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats, br.ring, br.ring_rows,     \
-                               br.lo, br.inv_w, br.n_bins);                                       \
+        if constexpr (!BINS) {            /* the streamed row form: plain per-step launches only */ \
+            if (a.stream_rows) {                                                                  \
+                if (packed) FIVEEQ_STEP_LAUNCH(P, p0, p1, p2, true);                              \
+                else FIVEEQ_STEP_LAUNCH(T, p0, p1, p2, true);                                     \
+                break;                                                                            \
+            }                                                                                     \
+        }                                                                                         \
+        if (packed) FIVEEQ_STEP_LAUNCH(P, p0, p1, p2, false);                                     \
+        else FIVEEQ_STEP_LAUNCH(T, p0, p1, p2, false);                                            \
         break;
         FIVEEQ_LAYOUTS(X)
 #undef X
+#undef FIVEEQ_STEP_LAUNCH
         default:
             return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
     }
@@ -268,6 +292,9 @@ int make_args(RunArgs<T>& a, const fiveeq_model* m, int64_t n, int64_t ld, const
     a.n_steps = n_steps;
     a.stats = stats;
     a.packing = g_f32_packing.load(std::memory_order_relaxed);
+    int sum_pools = 0;
+    for (int g = 0; g < m->n_gas; ++g) sum_pools += m->gas[g].n_pools;
+    a.stream_rows = rows_streamed(g_row_policy.load(std::memory_order_relaxed), m->n_gas, sum_pools, n, ld, (int)sizeof(T));
     return FIVEEQ_OK;
 }
 
@@ -622,6 +649,20 @@ int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t* n_pools) {
 }
 int fiveeq_set_f32_packing(int on) { return g_f32_packing.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 
+int fiveeq_set_row_policy(int32_t policy) {
+    if (policy != FIVEEQ_ROWS_AUTO && policy != FIVEEQ_ROWS_CACHED && policy != FIVEEQ_ROWS_STREAMED)
+        return fail(FIVEEQ_E_INVALID, "row policy %d: want FIVEEQ_ROWS_CACHED (0), _STREAMED (1) or _AUTO (2)", policy);
+    return g_row_policy.exchange(policy, std::memory_order_relaxed);
+}
+
+int fiveeq_rows_streamed(int32_t n_gas, const int32_t* n_pools, int64_t n_members, int64_t ld, int32_t word_bytes) {
+    if (n_gas < 1 || n_gas > FIVEEQ_MAX_GAS || !n_pools || n_members < 0 || ld < n_members || (word_bytes != 4 && word_bytes != 8))
+        return fail(FIVEEQ_E_INVALID, "fiveeq_rows_streamed: bad shape");
+    int sum_pools = 0;
+    for (int g = 0; g < n_gas; ++g) sum_pools += n_pools[g];
+    return rows_streamed(g_row_policy.load(std::memory_order_relaxed), n_gas, sum_pools, n_members, ld, word_bytes) ? 1 : 0;
+}
+
 static int lhs_check(int64_t n_total, int64_t m0, int64_t n_members, int32_t dim0, int32_t n_dim, int64_t ld) {
     // 2^28: stratum (28 bits) + the 24-bit jitter placed mid-cell (25 fractional bits) is then an EXACT fp64 sum, so u lies
     // strictly inside its stratum; beyond that the sum would round and could touch the stratum edge
@@ -713,6 +754,24 @@ int fiveeq_stream_copy_wide_f64(int64_t n, const double* src, double* dst, void*
     const int64_t blocks = tiles < 16384 ? tiles : 16384;
     hipLaunchKernelGGL(fiveeq::stream_copy_wide_kernel, dim3((unsigned)blocks), dim3(FIVEEQ_BLOCK), 0, (hipStream_t)stream,
                        n2, reinterpret_cast<const double2*>(src), reinterpret_cast<double2*>(dst));
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
+int fiveeq_busy(int64_t iterations, double* out, void* stream) {
+    if (iterations < 0 || iterations > 100000000LL) return fail(FIVEEQ_E_INVALID, "iterations=%lld outside 0..1e8", (long long)iterations);
+    if (!out) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    hipLaunchKernelGGL(fiveeq::busy_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, iterations, out);
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
+int fiveeq_stream_copy_nt_f64(int64_t n, const double* src, double* dst, void* stream) {
+    if (n < 1 || n % (4 * FIVEEQ_BLOCK)) return fail(FIVEEQ_E_INVALID, "n=%lld must be a positive multiple of %d", (long long)n, 4 * FIVEEQ_BLOCK);
+    if (!src || !dst) return fail(FIVEEQ_E_INVALID, "NULL device pointer");
+    const int64_t blocks = n / (4 * FIVEEQ_BLOCK);
+    if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n too large for one launch");
+    hipLaunchKernelGGL(fiveeq::stream_copy_nt_kernel, dim3((unsigned)blocks), dim3(FIVEEQ_BLOCK), 0, (hipStream_t)stream, n, src, dst);
     HIP_TRY(hipGetLastError());
     return FIVEEQ_OK;
 }

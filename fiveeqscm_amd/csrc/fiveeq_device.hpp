@@ -16,7 +16,7 @@
 //   3   hfc_conc_kernel    the reference's one function over an ensemble
 //   4   hist_rows_kernel   fixed-bin histograms (+ moments) of rows: the pass of the streamed histogram pipelines
 //   5   lhs_kernel         shard-computable Latin hypercube (keyed Feistel bijection)
-//   diagnostics: stream_copy_kernel, stream_copy_wide_kernel, math_probe_kernel
+//   diagnostics: stream_copy_kernel, stream_copy_wide_kernel, stream_copy_nt_kernel, math_probe_kernel, busy_kernel
 // All model arithmetic is member_step(): every kernel that steps the model gives the same bits.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -558,6 +558,22 @@ __device__ __forceinline__ void store_lane(float* p, float2v v, bool full) {
     if (full) *reinterpret_cast<float2v*>(p) = v;
     else *p = v.x;
 }
+// The same with the NON-TEMPORAL policy (NT = true): rows that are read or written once per pass over an ensemble far larger
+// than the Infinity Cache, where keeping them resident cannot pay (step_kernel's STREAM form).
+template <typename V, bool NT>
+__device__ __forceinline__ V load_row(const typename Lane<V>::S* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    else return load_lane<V>(p);
+}
+template <bool NT, typename S, typename V>
+__device__ __forceinline__ void store_row(S* p, V v, bool full) {
+    if constexpr (!NT) store_lane(p, v, full);
+    else if constexpr (sizeof(V) == sizeof(S)) __builtin_nontemporal_store(v, p);
+    else {
+        if (full) __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+        else __builtin_nontemporal_store(v.x, p);
+    }
+}
 
 // ---------------------------------------------------------------------------------
 // The time-fused kernel produces one T per lane EVERY step, so it batches the statistics instead
@@ -722,6 +738,15 @@ __device__ __forceinline__ void wave_stats_flush(const float2v* tile /* [STAT_ST
 // dispatch granularity and a trivial barrier: -2 % at 1M members, -3 % at 8M, -7 % at 100k against
 // 256-thread workgroups with identical buffers, profiles/r01/ab_variants.txt) and owns the same
 // members in every launch.
+// CACHE POLICY OF THE ROWS (round 5, profiles/r05/step_row_policy_ab.txt, hbm_rates.txt):
+//   * the stored C / T rows are written with the NON-TEMPORAL policy in every form: written once, never read by a stepping
+//     kernel, they only displace state and parameter rows from the 256 MiB Infinity Cache that the next step would have hit
+//     (-1.4 % per step at 1M fp64 members, -1 % at the 1.25M shard, -3...-8 % on chunk-major runs of 8-25M members);
+//   * NT = true (the STREAMED form): state and parameter rows too.  For a launch whose rows cannot survive until the next
+//     step anyway — far more members than the cache holds, not scheduled chunk-major — the default policy only adds
+//     allocate-and-evict work to every access: -4.5 % per step at 8M fp64 members (0.676 -> 0.707 of 8 TB/s), -9 % at 4M;
+//     on a cache-resident ensemble it is the WRONG form (+11...13 % at 1-2M members).  The host picks per call
+//     (fiveeq_capi.hip, rows_streamed()).  Same arithmetic: the same bits.
 // ---------------------------------------------------------------------------------
 // BINS = true: the streamed-histogram form.  Besides everything above, the kernel writes the histogram BIN INDEX of T of every
 // step (fiveeq_hist_rows' bin rule, bit for bit; 0xFFFF for a NaN) as one uint16 per member into a ring
@@ -794,7 +819,7 @@ __device__ __forceinline__ unsigned int hist_bin2(const HistRule<float> r, const
 #else
 #define FIVEEQ_STEP_ATTR
 #endif
-template <typename V, int P0, int P1, int P2, bool BINS = false>
+template <typename V, int P0, int P1, int P2, bool BINS = false, bool NT = false>
 __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kernel(
     const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps, const int t,
     const int64_t n, const int64_t ld,
@@ -808,6 +833,7 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
     using L = Layout<P0, P1, P2>;
     using T = typename Lane<V>::S;
     constexpr int W = Lane<V>::W;                 // members per lane
+    constexpr bool NTT = true;                    // the stored C / T rows: written once, never read by a stepping kernel
     __shared__ T drv[DRIVE_STRIDE];
     const int64_t m = ((int64_t)blockIdx.x * FIVEEQ_STEP_BLOCK + threadIdx.x) * W;     // this lane's first member
     const bool active = m < n;
@@ -829,13 +855,13 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
 
     V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G];
 #pragma unroll
-    for (int k = 0; k < L::SP; ++k) Rv[k] = load_lane<V>(R + k * ld + mm);
+    for (int k = 0; k < L::SP; ++k) Rv[k] = load_row<V, NT>(R + k * ld + mm);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) Sv[k] = load_lane<V>(S + k * ld + mm);
+    for (int k = 0; k < 2; ++k) Sv[k] = load_row<V, NT>(S + k * ld + mm);
 #pragma unroll
-    for (int k = 0; k < 3 * L::G; ++k) rr[k] = load_lane<V>(r + k * ld + mm);
+    for (int k = 0; k < 3 * L::G; ++k) rr[k] = load_row<V, NT>(r + k * ld + mm);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) qq[k] = load_lane<V>(q + k * ld + mm);
+    for (int k = 0; k < 2; ++k) qq[k] = load_row<V, NT>(q + k * ld + mm);
 
     if (threadIdx.x < NW) reinterpret_cast<T*>(&km_s)[threadIdx.x] = stage_v;
     if (threadIdx.x < DRIVE_STRIDE) drv[threadIdx.x] = drv_v;
@@ -846,17 +872,17 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
         member_step<V, L>(kmr, drv, rr, qq, Rv, Sv, Cv, Tn);
         if (active) {
 #pragma unroll
-        for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);
+        for (int k = 0; k < L::SP; ++k) store_row<NT>(R + k * ld + m, Rv[k], full);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) store_lane(S + k * ld + m, Sv[k], full);
+        for (int k = 0; k < 2; ++k) store_row<NT>(S + k * ld + m, Sv[k], full);
         const int row = __builtin_amdgcn_readfirstlane((int)drv[7]);     // wave-uniform: scalar test + offsets
         if (row >= 0 && row < n_rows) {
             if (C_traj != nullptr) {
                 T* c = C_traj + (int64_t)row * L::G * ld + m;
 #pragma unroll
-                for (int g = 0; g < L::G; ++g) store_lane(c + g * ld, Cv[g], full);
+                for (int g = 0; g < L::G; ++g) store_row<NTT>(c + g * ld, Cv[g], full);
             }
-            if (T_traj != nullptr) store_lane(T_traj + (int64_t)row * ld + m, Tn, full);
+            if (T_traj != nullptr) store_row<NTT>(T_traj + (int64_t)row * ld + m, Tn, full);
         }
         if constexpr (BINS) {                                            // the histogram bin of T, 2 bytes per member
             unsigned short* o = bin_ring + (int64_t)(t % ring_rows) * ld + m;
@@ -1950,6 +1976,30 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void stream_copy_wide_kernel(const in
             for (int64_t j = i; j < n2; j += FIVEEQ_BLOCK) dst[j] = src[j];
         }
     }
+}
+
+// The copy with the NON-TEMPORAL policy on both sides: 8 B per lane, four loads in flight, one workgroup per 8 KiB tile
+// (tools/microbench/hbm_rates.hip: the fastest copy of the shapes tried on MI355X, 6.3 TB/s against 5.6-5.8 for the default
+// policy at either width — nothing of a 2 GiB copy is worth keeping in the Infinity Cache).  n a multiple of 1024.
+__global__ __launch_bounds__(FIVEEQ_BLOCK) void stream_copy_nt_kernel(const int64_t n, const double* __restrict__ src,
+                                                                      double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * (4 * FIVEEQ_BLOCK) + threadIdx.x;
+    if (i + 3 * FIVEEQ_BLOCK >= n) return;
+    const double v0 = __builtin_nontemporal_load(src + i), v1 = __builtin_nontemporal_load(src + i + FIVEEQ_BLOCK),
+                 v2 = __builtin_nontemporal_load(src + i + 2 * FIVEEQ_BLOCK), v3 = __builtin_nontemporal_load(src + i + 3 * FIVEEQ_BLOCK);
+    __builtin_nontemporal_store(v0, dst + i);
+    __builtin_nontemporal_store(v1, dst + i + FIVEEQ_BLOCK);
+    __builtin_nontemporal_store(v2, dst + i + 2 * FIVEEQ_BLOCK);
+    __builtin_nontemporal_store(v3, dst + i + 3 * FIVEEQ_BLOCK);
+}
+
+// A kernel that does nothing for a known time: ONE wave, `iters` dependent fp64 FMAs (~3.5 ns each).  The host uses two of
+// them to find out whether two HIP streams really run side by side (streams that share a hardware queue do not:
+// fiveeqscm_amd/tuning.py, concurrent_side_streams).  Bounded by construction: the host caps iters.
+__global__ __launch_bounds__(64) void busy_kernel(const int64_t iters, double* __restrict__ out) {
+    double x = 1.0e-9 * (double)threadIdx.x;
+    for (int64_t i = 0; i < iters; ++i) x = fe_fma(x, 0.999999, 1.0e-9);
+    if (threadIdx.x == 0) out[0] = x;
 }
 
 }  // namespace fiveeq

@@ -28,10 +28,14 @@ from . import _capi
 from .checkpoint import CheckpointMixin
 from .emissions import make_drive
 from .params import make_model, n_gas_of, pools_of
-from .tuning import _env_choice, _env_positive, calibrate  # noqa: F401  (calibrate: part of this module's interface)
+from .tuning import _env_choice, _env_positive, calibrate, concurrent_side_streams  # noqa: F401  (calibrate: part of this module's interface)
 
 _DTYPES = {torch.float64: "f64", torch.float32: "f32"}
 INFINITY_CACHE_BYTES = 256 << 20     # MI355X die-level L3 (MI355X_MICROARCH.md); sizes the chunk-major schedule
+# ... whose chunks hold this share of it in state + parameter rows: the per-step rate is flat from 0.55 to 0.85 of the cache and
+# falls off above (8M fp64 members, two streams: 0.88-0.89 of 8 TB/s up to 0.8, 0.82-0.84 at 0.9-0.95; 25M fp32: 0.905-0.914 up
+# to 0.85, 0.844 at 0.95; profiles/r05/chunk_share_sweep.txt).  Rounds 2-4 filled the whole cache (0.965 after rounding).
+CHUNK_CACHE_SHARE = 0.7
 
 
 # The two box-dependent figures the schedules are derived from.  The defaults are what rounds 1-3 measured on MI355X; another
@@ -213,7 +217,6 @@ class EnsembleEngine(CheckpointMixin):
         if small_lanes != "auto" and int(small_lanes) not in (1, 4):
             raise ValueError("small_lanes must be 'auto', 1 or 4")
         self.small_lanes = small_lanes if small_lanes == "auto" else int(small_lanes)
-        self._ps_side = []                  # side streams of the per-step parts, created on first use
         self._ps_unjoined = False           # run(..., join=False) left work on the side streams the caller's has not waited for
         self._R0 = None if R0 is None else np.asarray(R0, dtype=np.float64).reshape(SP, N)
         self._S0 = None if S0 is None else np.asarray(S0, dtype=np.float64).reshape(2, N)
@@ -224,11 +227,11 @@ class EnsembleEngine(CheckpointMixin):
 
     @staticmethod
     def auto_chunk(n_members, sum_pools, n_gas, dtype, cache_bytes=INFINITY_CACHE_BYTES):
-        """Members per chunk such that one chunk's state + parameter rows fill the Infinity Cache
-        (rounded down to 65536 members); 0 = do not chunk (the ensemble is < 1.5 chunks)."""
+        """Members per chunk such that one chunk's state + parameter rows take CHUNK_CACHE_SHARE of the Infinity Cache
+        (rounded down to 65536 members); 0 = do not chunk (the ensemble is < 1.5 chunks: its rows about fit the cache)."""
         w = 8 if dtype == torch.float64 else 4
         resident = w * (sum_pools + 2 + 3 * n_gas + 2)
-        c = (int(cache_bytes) // resident) // 65536 * 65536
+        c = int(CHUNK_CACHE_SHARE * cache_bytes / resident) // 65536 * 65536
         return c if n_members > c + c // 2 else 0
 
     def fused_span_steps(self, n_steps):
@@ -436,9 +439,11 @@ class EnsembleEngine(CheckpointMixin):
         """The HIP streams mode='per_step' launches on: the caller's, then the side streams of the other parts."""
         main = stream if stream is not None else torch.cuda.current_stream(self.device)
         n_streams = 1 + max(i for _, _, i in self.per_step_launches())
-        while len(self._ps_side) < n_streams - 1:
-            self._ps_side.append(torch.cuda.Stream(device=self.device))
-        return [main] + self._ps_side[:n_streams - 1]
+        if n_streams == 1:
+            return [main]
+        # side streams that were PROBED to run beside `main` (tuning.concurrent_side_streams: a stream that shares main's
+        # hardware queue serialises the parts, +12 % per step); one probe per (device, main) and process, ~10 ms
+        return [main] + concurrent_side_streams(self.lib, main, n_streams - 1)
 
     def join(self, stream=None):
         """Make the caller's stream wait for everything run(..., join=False) enqueued on the side streams."""
@@ -515,7 +520,7 @@ class EnsembleEngine(CheckpointMixin):
             torch.cuda.synchronize(dev)
             self._bins = None
             self._bins = ring = {"S": S, "buf": torch.empty((slots, S, N), dtype=torch.int16, device=dev),
-                                 "side": torch.cuda.Stream(device=dev), "drained": [torch.cuda.Event(), torch.cuda.Event()]}
+                                 "drained": [torch.cuda.Event(), torch.cuda.Event()]}
         return ring
 
     def _run_fused_bin_ring(self, t_begin, t_end, stream):
@@ -528,7 +533,7 @@ class EnsembleEngine(CheckpointMixin):
         ring = self._bin_ring()
         S = ring["S"]
         main = stream if stream is not None else torch.cuda.current_stream(dev)
-        side = main if self.hist_pass_stream == "same" else ring["side"]
+        side = main if self.hist_pass_stream == "same" else concurrent_side_streams(self.lib, main, 1)[0]
         side.wait_stream(main)
         fused = self._fn("run_fused_bins")
         lo_h, hi_h, nb = self.hist_spec

@@ -59,3 +59,71 @@ def calibrate(device="cuda:0", members=1_000_000, apply=True):
     if apply:
         engine.LAUNCH_BOUNDARY_S, engine.HBM_STREAM_BYTES_PER_S = out["launch_boundary_s"], out["hbm_stream_bytes_per_s"]
     return out
+
+
+# ---- side streams that really run beside the caller's stream ------------------------------------------------------------------
+# HIP maps its streams onto a handful of hardware queues (four by default) in creation order, and two streams on the same queue
+# run one after the other whatever the program says.  A schedule that overlaps two launches (the two member parts of a per-step
+# launch, the histogram pass beside the next fused chunk) then silently loses its overlap: the per-step form is 12 % slower
+# (4M fp64 members: 158 us per step instead of 141) for every fourth stream torch hands out (profiles/r05/side_stream_probe.txt).
+# So the side streams are PROBED: two launches of known duration (fiveeq_busy, one wave each) on the caller's stream and on the
+# candidate take the time of one when the streams are concurrent and of two when they are not.  The answer depends on the pair of
+# streams only: it is cached per (device, caller's stream) and shared by every engine of the process.
+_SIDE_STREAMS = {}
+_PROBE_ITERS = 60_000            # ~0.2 ms per launch: far above the launch and synchronisation overheads around it
+_PROBE_CANDIDATES = 8
+
+
+def _pair_time(lib, a, b, scratch, iters):
+    """Wall time (s) of one busy launch on stream a and — b given — another on b, both behind the same start."""
+    import ctypes
+    import time
+
+    import torch
+    a.synchronize()
+    if b is not None:
+        b.synchronize()
+    ptr = lambda i: ctypes.c_void_p(scratch.data_ptr() + 8 * i)   # noqa: E731
+    t0 = time.perf_counter()
+    lib.fiveeq_busy(iters, ptr(0), ctypes.c_void_p(a.cuda_stream))
+    if b is not None:
+        lib.fiveeq_busy(iters, ptr(1), ctypes.c_void_p(b.cuda_stream))
+        b.synchronize()
+    a.synchronize()
+    return time.perf_counter() - t0
+
+
+def streams_concurrent(lib, a, b, scratch=None):
+    """True when launches on HIP streams a and b (torch.cuda.Stream) overlap on this box right now: best of three timings of a
+    pair of one-wave launches against best of three of a single one.  Synchronises both streams."""
+    import torch
+    if a.cuda_stream == b.cuda_stream:
+        return False
+    with torch.cuda.device(a.device):
+        if scratch is None:
+            scratch = torch.zeros(2, dtype=torch.float64, device=a.device)
+        _pair_time(lib, a, b, scratch, 1000)                                   # code object load, clocks
+        one = min(_pair_time(lib, a, None, scratch, _PROBE_ITERS) for _ in range(3))
+        two = min(_pair_time(lib, a, b, scratch, _PROBE_ITERS) for _ in range(3))
+    return two < 1.5 * one
+
+
+def concurrent_side_streams(lib, main, count):
+    """`count` HIP streams on main's device that run beside `main` AND beside each other, probed once per (device, main) and
+    shared by every caller in the process.  A candidate that fails the probe is dropped (torch recycles its pool of streams, so
+    nothing leaks); if no candidate passes within _PROBE_CANDIDATES tries the last one is taken as it is — correctness never
+    depends on the overlap."""
+    import torch
+    key = (main.device.index, main.cuda_stream)
+    have = _SIDE_STREAMS.setdefault(key, [])
+    if len(have) < count:
+        with torch.cuda.device(main.device):
+            scratch = torch.zeros(2, dtype=torch.float64, device=main.device)
+            while len(have) < count:
+                cand = None
+                for _ in range(_PROBE_CANDIDATES):
+                    cand = torch.cuda.Stream(device=main.device)
+                    if all(streams_concurrent(lib, s, cand, scratch) for s in [main] + have):
+                        break
+                have.append(cand)
+    return have[:count]

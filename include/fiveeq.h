@@ -19,10 +19,11 @@
  *     passes torch-ROCm tensor data_ptr()s).  The library allocates nothing on
  *     the device, never synchronises the stream (launches are asynchronous) and is
  *     safe to call concurrently from several threads on different streams / devices.
- *     ALL the state it keeps: the thread-local error string (fiveeq_last_error), and ONE
- *     process-wide word, the fp32 packing switch of fiveeq_set_f32_packing — an atomic that
- *     every call reads once, so a call in flight while another thread flips it runs
- *     entirely with the old or entirely with the new setting (both give the same bits).
+ *     ALL the state it keeps: the thread-local error string (fiveeq_last_error), and TWO
+ *     process-wide words, the fp32 packing switch of fiveeq_set_f32_packing and the row cache
+ *     policy of fiveeq_set_row_policy — atomics that every call reads once, so a call in flight
+ *     while another thread flips one runs entirely with the old or entirely with the new setting
+ *     (every setting gives the same bits).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *   - Return value: 0 = success; <0 = error (FIVEEQ_E_*), message retrievable
  *     with fiveeq_last_error() on the same thread.  Arguments are validated on
@@ -52,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   9
+#define FIVEEQ_ABI_VERSION   10
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
@@ -234,6 +235,24 @@ int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t *n_pools);
  * Process-wide (an atomic word, see CONVENTIONS); meant for measurements and tests. */
 int fiveeq_set_f32_packing(int on);
 
+/* CACHE POLICY OF THE PER-STEP KERNEL'S ROWS (new).  The step / run / plan_create entry points read every state and parameter
+ * row once per step.  While those rows fit the 256 MiB Infinity Cache they are served from it at the next step (the default
+ * policy; what a chunk-major schedule arranges for large ensembles).  A launch whose rows cannot survive until the next step
+ * takes the STREAMED form instead: the same kernel with non-temporal loads and stores (bit-identical results; -4.5 % per step
+ * at 8M fp64 members, -9 % at 4M; +11...13 % — the wrong form — on a cache-resident 1-2M-member ensemble).
+ * FIVEEQ_ROWS_AUTO (the default) decides per call: streamed when n_members x (SP + 2 + 3G + 2) words >= the cache AND
+ * ld x the same >= twice the cache (ld = the row length: the whole ensemble this call's members are a sub-range of).
+ * fiveeq_set_row_policy forces one form process-wide (an atomic word read once per call, see CONVENTIONS; returns the previous
+ * setting, or FIVEEQ_E_INVALID for a value that is none of the three) — meant for measurements and tests.
+ * fiveeq_rows_streamed: 1 / 0 = the form a per-step launch of that shape would take now.  The stored C / T rows are written
+ * non-temporally in every form (written once, never re-read by a stepping kernel).  The streamed-histogram per-step form
+ * (fiveeq_run_bins_*) always takes the default policy. */
+#define FIVEEQ_ROWS_CACHED      0
+#define FIVEEQ_ROWS_STREAMED    1
+#define FIVEEQ_ROWS_AUTO        2
+int fiveeq_set_row_policy(int32_t policy);
+int fiveeq_rows_streamed(int32_t n_gas, const int32_t *n_pools, int64_t n_members, int64_t ld, int32_t word_bytes);
+
 /* CONCENTRATION-DRIVEN (inverse) mode (the reference's module name
  * `concentrations` hints at it, no reference code exists).  drive[t][0..2] hold the TARGET
  * concentration of each gas at the end of step t (shared by all members; columns 3..5 unused);
@@ -378,6 +397,14 @@ int fiveeq_lhs_rows_host_f64(uint64_t seed, int64_t n_total, int64_t m0, int64_t
 int fiveeq_stream_copy_f64(int64_t n, const double *src, double *dst, void *stream);
 /* the same copy with 16 B per lane (n even, pointers 16-byte aligned): the box's best plain copy */
 int fiveeq_stream_copy_wide_f64(int64_t n, const double *src, double *dst, void *stream);
+/* the same copy, 8 B per lane, NON-TEMPORAL loads and stores, one workgroup per 8 KiB (n a multiple of 1024): the fastest
+ * plain copy measured on MI355X (tools/microbench/hbm_rates.hip) — the ceiling bench.py's hbm_resident figure is held against */
+int fiveeq_stream_copy_nt_f64(int64_t n, const double *src, double *dst, void *stream);
+/* new — diagnostic: ONE wave that runs `iterations` (0..1e8) dependent fp64 FMAs (~3.5 ns each) and writes one double to
+ * `out`: a launch of known duration that occupies one SIMD.  Two of them on two streams take the time of one when the streams
+ * run side by side and of two when they share a hardware queue — how the Python host picks the side streams of its two-stream
+ * schedules (a stream that shares the caller's hardware queue costs the per-step form +12 %). */
+int fiveeq_busy(int64_t iterations, double *out, void *stream);
 
 /* new — diagnostic: y[i] = f(x[i]) with one of the kernels' own fp64 math primitives, so tests can
  * pin each against a CPU libm to the ulp.  op: 0 expm1 (x <= 0), 1 exp, 2 log (x > 0, finite normal),

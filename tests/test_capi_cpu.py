@@ -266,6 +266,7 @@ def test_concurrent_calls_and_the_packing_switch():
         v = 0
         while not stop.is_set():
             lib.fiveeq_set_f32_packing(v)
+            lib.fiveeq_set_row_policy(v)                       # the other process-wide word (ABI v10)
             v ^= 1
 
     threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
@@ -279,6 +280,31 @@ def test_concurrent_calls_and_the_packing_switch():
     flip.join()
     assert not errors, errors[:3]
     assert lib.fiveeq_set_f32_packing(1) in (0, 1) and lib.fiveeq_set_f32_packing(1) == 1
+    assert lib.fiveeq_set_row_policy(2) in (0, 1) and lib.fiveeq_set_row_policy(2) == 2
+
+
+def test_row_policy_rule_and_switch():
+    """include/fiveeq.h, "CACHE POLICY OF THE PER-STEP KERNEL'S ROWS": the rule as documented (a launch takes the streamed
+    form when its own rows fill the 256 MiB Infinity Cache and the ensemble is at least two caches), on the shapes the engine
+    produces — whole ensembles, the halves of a two-stream split, the chunks of the chunk-major schedule — and the switch."""
+    torch = pytest.importorskip("torch")
+    from fiveeqscm_amd.engine import EnsembleEngine
+    lib = _capi.load()
+    multigas, co2 = (ctypes.c_int32 * 3)(4, 1, 1), (ctypes.c_int32 * 1)(4)
+    q = lambda pools, G, n, ld, w: lib.fiveeq_rows_streamed(G, pools, n, ld, w)   # noqa: E731
+    assert lib.fiveeq_set_row_policy(2) in (0, 1, 2)                              # FIVEEQ_ROWS_AUTO
+    assert [q(multigas, 3, n, n, 8) for n in (1_000_000, 2_000_000, 3_000_000, 4_000_000, 8_000_000)] == [0, 0, 0, 1, 1]
+    assert q(multigas, 3, 2_000_000, 4_000_000, 8) == 1 and q(multigas, 3, 1_000_000, 4_000_000, 8) == 0   # halves / quarters of 4M
+    assert q(multigas, 3, 12_500_000, 12_500_000, 4) == 1 and q(co2, 1, 1_000_000, 1_000_000, 8) == 0
+    for n_total, dtype, w in ((8_000_000, torch.float64, 8), (12_500_000, torch.float32, 4), (100_000_000, torch.float32, 4)):
+        chunk = EnsembleEngine.auto_chunk(n_total, 6, 3, dtype)
+        assert chunk and q(multigas, 3, chunk, n_total, w) == 0, (n_total, chunk)   # chunk-major launches stay cache-resident
+    assert lib.fiveeq_set_row_policy(1) == 2 and q(co2, 1, 64, 64, 8) == 1        # forced: streamed
+    assert lib.fiveeq_set_row_policy(0) == 1 and q(multigas, 3, 8_000_000, 8_000_000, 8) == 0
+    assert lib.fiveeq_set_row_policy(5) == _capi.E_INVALID and b"row policy 5" in lib.fiveeq_last_error()
+    assert lib.fiveeq_set_row_policy(2) == 0                                       # the rejected value changed nothing
+    assert lib.fiveeq_rows_streamed(4, multigas, 10, 10, 8) == _capi.E_INVALID and lib.fiveeq_rows_streamed(3, multigas, 10, 5, 8) == _capi.E_INVALID
+    assert lib.fiveeq_rows_streamed(3, multigas, 10, 10, 2) == _capi.E_INVALID
 
 
 def test_abi_v5_host_side_guards():

@@ -1178,9 +1178,11 @@ def test_chunk_major_schedule_is_bit_identical(gpu, mode):
     assert auto.chunk_members == 0                      # small ensembles are not chunked
     big = prm.default_params("multigas")
     from fiveeqscm_amd.engine import EnsembleEngine
-    assert EnsembleEngine.auto_chunk(8_000_000, 6, 3, torch.float64) == 1_703_936
-    assert EnsembleEngine.auto_chunk(1_000_000, 6, 3, torch.float64) == 0
-    assert EnsembleEngine.auto_chunk(12_500_000, 6, 3, torch.float32) == 3_473_408
+    # a chunk's state + parameter rows take 0.7 of the 256 MiB cache (profiles/r05/chunk_share_sweep.txt); ensembles whose rows
+    # about fit it (the 1M bench workload, the 1.25M config-4 shard) are not chunked
+    assert EnsembleEngine.auto_chunk(8_000_000, 6, 3, torch.float64) == 1_179_648 == int(0.7 * (256 << 20) / 152) // 65536 * 65536
+    assert EnsembleEngine.auto_chunk(1_000_000, 6, 3, torch.float64) == 0 == EnsembleEngine.auto_chunk(1_250_000, 6, 3, torch.float64)
+    assert EnsembleEngine.auto_chunk(12_500_000, 6, 3, torch.float32) == 2_424_832
     chunked.close()
     plain.close()
 
@@ -1321,6 +1323,9 @@ def test_whole_config5_ensemble_on_one_gpu(gpu):
     eng.run(0, 10, mode="per_step")
     torch.cuda.synchronize()
     assert torch.equal(eng.T[0], T9) and torch.equal(eng.C[0], C9)
+    eng.close()
+    del eng, pd, T9, C9, x
+    torch.cuda.empty_cache()                                     # ~60 GB back to the device for the tests that follow
 
 
 def test_full_size_config3_direct_parity_of_final_state(gpu):
@@ -1506,6 +1511,83 @@ def test_per_step_parts_on_two_streams_are_bit_identical(gpu):
     t_1m = 1_000_000 * 248 / eng_mod.HBM_STREAM_BYTES_PER_S
     assert t_1m >= eng_mod.PER_STEP_SPLIT_MIN_S > 250_000 * 248 / eng_mod.HBM_STREAM_BYTES_PER_S
     small.close()
+
+
+def test_streamed_rows_are_bit_identical_and_picked_for_the_launches_that_cannot_stay_cached(gpu):
+    """include/fiveeq.h, "CACHE POLICY OF THE PER-STEP KERNEL'S ROWS": the STREAMED form of the per-step kernel (non-temporal
+    loads and stores of the state and parameter rows) is the same arithmetic — per-step, step-by-step and graph replay, both
+    precisions (packed and scalar fp32 lanes), several layouts, ragged sizes, sub-ranges: bit for bit — and the library's own
+    rule takes it exactly for the launches whose rows cannot survive until the next step."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    CACHED, STREAMED, AUTO = 0, 1, 2
+    n_steps = 40
+    try:
+        for kind, G, N, td in (("multigas", 3, 70_001, torch.float64), ("multigas", 3, 70_001, torch.float32),
+                               ("multigas", 3, 70_002, torch.float32), ("co2", 1, 4097, torch.float64), ("co2", 1, 1, torch.float32)):
+            E = emi.rcp_like_emissions(750, G)[240:240 + n_steps]
+            p = prm.sample_ensemble(prm.default_params(kind), N, seed=5)
+            out = {}
+            for policy in (CACHED, STREAMED):
+                lib.fiveeq_set_row_policy(policy)
+                eng = _engine(p, N, E, dtype=td, collect_stats=True, per_step_streams=2 if N > 1024 else 1)
+                eng.run(0, 11, mode="per_step")
+                for t in range(11, 15):
+                    eng.step(t)
+                eng.run(15, n_steps, mode="graph")
+                torch.cuda.synchronize()
+                out[policy] = [getattr(eng, name).clone() for name in ("C", "T", "R", "S", "T_stats")]
+                eng.close()
+            for a, b, name in zip(out[CACHED], out[STREAMED], ("C", "T", "R", "S", "T_stats")):
+                assert torch.equal(a, b), (kind, N, td, name)
+        # the rule, end to end: an 8M-member fp64 ensemble run unchunked streams, its chunk-major schedule does not
+        lib.fiveeq_set_row_policy(AUTO)
+        pools = (ctypes.c_int32 * 3)(4, 1, 1)
+        N = 8_000_000
+        big = _engine(prm.sample_ensemble_shard(prm.default_params("multigas"), N, device=gpu), N,
+                      emi.rcp_like_emissions(750, 3)[240:252], output_steps=[11])
+        assert big.chunk_members and all(lib.fiveeq_rows_streamed(3, pools, n, N, 8) == 0 for _, n, _ in big.per_step_launches())
+        big.run(mode="per_step")
+        torch.cuda.synchronize()
+        T_chunked, R_chunked = big.T.clone(), big.R.clone()
+        big.chunk_members = 0
+        assert all(lib.fiveeq_rows_streamed(3, pools, n, N, 8) == 1 for _, n, _ in big.per_step_launches())
+        big.reset_state()
+        big.run(mode="per_step")
+        torch.cuda.synchronize()
+        assert torch.equal(big.T, T_chunked) and torch.equal(big.R, R_chunked)
+        big.close()
+    finally:
+        lib.fiveeq_set_row_policy(AUTO)
+
+
+def test_side_streams_are_probed_for_real_concurrency(gpu):
+    """fiveeqscm_amd/tuning.py: the side streams of the two-stream schedules are probed with a pair of one-wave launches of known
+    duration (fiveeq_busy): what the picker returns runs beside the caller's stream and beside each other; the choice is made
+    once per caller's stream; a stream is never concurrent with itself; the probe kernel validates its bound."""
+    from fiveeqscm_amd import _capi, tuning
+    lib = _capi.load()
+    main = torch.cuda.current_stream(gpu)
+    picked = tuning.concurrent_side_streams(lib, main, 2)
+    assert len(picked) == 2 and len({main.cuda_stream, picked[0].cuda_stream, picked[1].cuda_stream}) == 3
+    assert tuning.streams_concurrent(lib, main, picked[0]) and tuning.streams_concurrent(lib, main, picked[1])
+    assert tuning.streams_concurrent(lib, picked[0], picked[1])
+    assert not tuning.streams_concurrent(lib, main, main)
+    again = tuning.concurrent_side_streams(lib, main, 1)
+    assert again[0].cuda_stream == picked[0].cuda_stream
+    other = torch.cuda.Stream()
+    mine = tuning.concurrent_side_streams(lib, other, 1)
+    assert mine[0].cuda_stream != other.cuda_stream and tuning.streams_concurrent(lib, other, mine[0])
+    out = torch.zeros(1, dtype=torch.float64, device=gpu)
+    assert lib.fiveeq_busy(10, ctypes.c_void_p(out.data_ptr()), None) == _capi.OK
+    torch.cuda.synchronize()
+    assert 0.0 < out.item() < 1.0
+    assert lib.fiveeq_busy(10**9, ctypes.c_void_p(out.data_ptr()), None) == _capi.E_INVALID
+    assert lib.fiveeq_busy(-1, ctypes.c_void_p(out.data_ptr()), None) == _capi.E_INVALID
+    # and the engine uses them
+    eng = _engine(prm.sample_ensemble(prm.default_params("multigas"), 4096), 4096, emi.rcp_like_emissions(20, 3), per_step_streams=2)
+    assert [s.cuda_stream for s in eng.per_step_stream_list()] == [main.cuda_stream, picked[0].cuda_stream]
+    eng.close()
 
 
 def test_calibrate_measures_the_box_dependent_constants(gpu):

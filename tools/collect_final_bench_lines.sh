@@ -35,6 +35,8 @@ python3 bench.py --no-cpu-baseline --workload config5 --dtype f32 --steps 300 > 
 python3 bench.py --no-cpu-baseline --dtype f32 > $OUT/bench_config3_f32.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --dtype f32 --mode fused > $OUT/bench_config3_f32_fused.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --workload config5 --dtype f32 --mode fused --no-trajectory > $OUT/bench_config5_f32_fused_no_trajectory.json 2>/dev/null; echo bench13
+python3 bench.py --no-cpu-baseline --no-hbm-resident --workload config5 --dtype f32 --members 100000000 --no-trajectory > $OUT/bench_config5_whole_on_one_gpu_f32_per_step.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --no-hbm-resident --workload config5 --dtype f32 --members 100000000 --no-trajectory --mode fused > $OUT/bench_config5_whole_on_one_gpu_f32_fused.json 2>/dev/null; echo bench15
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-hbm-resident > $OUT/bench_config3_under_rocprof.json 2> $OUT/trace.err
 for k in kernel_stats domain_stats; do src=$(ls -t $OUT/trace/*/*_$k.csv 2>/dev/null | head -1); [ -n "$src" ] && cp "$src" $OUT/${k}_bench_config3.csv; done
