@@ -1584,6 +1584,14 @@ def test_side_streams_are_probed_for_real_concurrency(gpu):
     assert 0.0 < out.item() < 1.0
     assert lib.fiveeq_busy(10**9, ctypes.c_void_p(out.data_ptr()), None) == _capi.E_INVALID
     assert lib.fiveeq_busy(-1, ctypes.c_void_p(out.data_ptr()), None) == _capi.E_INVALID
+    # no candidate passes (a profiler that serialises kernels, a busy card): the last one is taken as it is — only overlap is lost
+    probe, tuning.streams_concurrent = tuning.streams_concurrent, lambda *a, **k: False
+    try:
+        lonely = torch.cuda.Stream()
+        got = tuning.concurrent_side_streams(lib, lonely, 1)
+        assert len(got) == 1 and got[0].cuda_stream != lonely.cuda_stream
+    finally:
+        tuning.streams_concurrent = probe
     # and the engine uses them
     eng = _engine(prm.sample_ensemble(prm.default_params("multigas"), 4096), 4096, emi.rcp_like_emissions(20, 3), per_step_streams=2)
     assert [s.cuda_stream for s in eng.per_step_stream_list()] == [main.cuda_stream, picked[0].cuda_stream]
