@@ -175,8 +175,8 @@ def parse():
                     help="device seconds to clock: the K-step block is repeated back to back until this much device time has "
                          "been clocked and the MEDIAN block is reported (0: time ONE block on the wall clock)")
     ap.add_argument("--max-repeats", type=int, default=20001)
-    ap.add_argument("--dist-timeout-s", type=float, default=90.0, help="timeout of every process group (init and collectives)")
-    ap.add_argument("--summary-watchdog-s", type=float, default=60.0,
+    ap.add_argument("--dist-timeout-s", type=float, default=120.0, help="timeout of every process group (init and collectives)")
+    ap.add_argument("--summary-watchdog-s", type=float, default=150.0,
                     help="N > 1: if the end-of-run exchange has not returned after this long, rank 0 prints the (complete) "
                          "line with summary.error and the job exits non-zero")
     ap.add_argument("--launch-timeout-s", type=float, default=570.0,
