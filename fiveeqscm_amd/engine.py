@@ -32,10 +32,13 @@ from .tuning import _env_choice, _env_positive, calibrate, concurrent_side_strea
 
 _DTYPES = {torch.float64: "f64", torch.float32: "f32"}
 INFINITY_CACHE_BYTES = 256 << 20     # MI355X die-level L3 (MI355X_MICROARCH.md); sizes the chunk-major schedule
-# ... whose chunks hold this share of it in state + parameter rows: the per-step rate is flat from 0.55 to 0.85 of the cache and
-# falls off above (8M fp64 members, two streams: 0.88-0.89 of 8 TB/s up to 0.8, 0.82-0.84 at 0.9-0.95; 25M fp32: 0.905-0.914 up
-# to 0.85, 0.844 at 0.95; profiles/r05/chunk_share_sweep.txt).  Rounds 2-4 filled the whole cache (0.965 after rounding).
-CHUNK_CACHE_SHARE = 0.7
+# ... whose chunks hold at most this share of it in state + parameter rows: the per-step rate of a chunk-major run is flat from
+# 0.55 to 0.85 of the cache and falls off above (8M fp64 members, two streams: 0.88-0.89 of 8 TB/s up to 0.8, 0.82-0.84 at
+# 0.9-0.95; 25M fp32: 0.905-0.914 up to 0.85, 0.844 at 0.95; profiles/r05/chunk_share_sweep.txt; rounds 2-4 filled the whole
+# cache, 0.965 after rounding).  An ensemble that fits the cache by itself is not chunked (0.91 up to 0.96 of the cache, 0.82 at
+# 1.02), and the chunks are EVEN: a small ragged last chunk runs its steps launch-bound (2.4M members as 1179648 + 1179648 +
+# 40704: 0.877; as 2 x 1.2M: 0.909; profiles/r05/chunk_share_sweep.txt, second table).
+CHUNK_CACHE_SHARE = 0.7              # (0.8 is as good or better at 4M, 16M and 25M members and 3.5 % worse at 8M: third table of that file)
 
 
 # The two box-dependent figures the schedules are derived from.  The defaults are what rounds 1-3 measured on MI355X; another
@@ -107,7 +110,7 @@ class EnsembleEngine(CheckpointMixin):
         Infinity Cache are scheduled chunk-major — all requested steps for members [0, c), then
         [c, 2c), ... — so each chunk's rows stay cache-resident between its consecutive launches
         (0.89-0.91 of 8 TB/s from 4M to 100M members against 0.70-0.79 streamed from HBM; bit-identical results: members
-        never interact).  "auto" sizes a chunk's rows to CHUNK_CACHE_SHARE of the cache; an int forces c; None / 0 disables it
+        never interact).  "auto" sizes a chunk's rows to at most CHUNK_CACHE_SHARE of the cache, in even chunks; an int forces c; None / 0 disables it
         (the library then runs such launches with non-temporal row accesses, include/fiveeq.h "CACHE POLICY").
         per_step_streams: mode='per_step' launches each timestep as this many kernels over contiguous member parts, each
         part's launches on its own HIP stream, so that one part's launch tail and ramp overlap the other part's kernel
@@ -228,12 +231,15 @@ class EnsembleEngine(CheckpointMixin):
 
     @staticmethod
     def auto_chunk(n_members, sum_pools, n_gas, dtype, cache_bytes=INFINITY_CACHE_BYTES):
-        """Members per chunk such that one chunk's state + parameter rows take CHUNK_CACHE_SHARE of the Infinity Cache
-        (rounded down to 65536 members); 0 = do not chunk (the ensemble is < 1.5 chunks: its rows about fit the cache)."""
+        """Members per chunk of the chunk-major schedule: the fewest EVEN chunks whose state + parameter rows take at most
+        CHUNK_CACHE_SHARE of the Infinity Cache each (a multiple of 256 members); 0 = do not chunk: the ensemble's rows fit the
+        cache by themselves."""
         w = 8 if dtype == torch.float64 else 4
-        resident = w * (sum_pools + 2 + 3 * n_gas + 2)
-        c = int(CHUNK_CACHE_SHARE * cache_bytes / resident) // 65536 * 65536
-        return c if n_members > c + c // 2 else 0
+        rows_bytes = n_members * w * (sum_pools + 2 + 3 * n_gas + 2)
+        if rows_bytes <= cache_bytes:
+            return 0
+        k = -(-rows_bytes // int(CHUNK_CACHE_SHARE * cache_bytes))
+        return -(-n_members // (256 * k)) * 256
 
     def fused_span_steps(self, n_steps):
         """Steps per launch mode='fused' uses for a request of n_steps steps (see fused_span); n_steps = one launch."""

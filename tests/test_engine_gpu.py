@@ -1178,11 +1178,16 @@ def test_chunk_major_schedule_is_bit_identical(gpu, mode):
     assert auto.chunk_members == 0                      # small ensembles are not chunked
     big = prm.default_params("multigas")
     from fiveeqscm_amd.engine import EnsembleEngine
-    # a chunk's state + parameter rows take 0.7 of the 256 MiB cache (profiles/r05/chunk_share_sweep.txt); ensembles whose rows
-    # about fit it (the 1M bench workload, the 1.25M config-4 shard) are not chunked
-    assert EnsembleEngine.auto_chunk(8_000_000, 6, 3, torch.float64) == 1_179_648 == int(0.7 * (256 << 20) / 152) // 65536 * 65536
-    assert EnsembleEngine.auto_chunk(1_000_000, 6, 3, torch.float64) == 0 == EnsembleEngine.auto_chunk(1_250_000, 6, 3, torch.float64)
-    assert EnsembleEngine.auto_chunk(12_500_000, 6, 3, torch.float32) == 2_424_832
+    # the fewest EVEN chunks whose state + parameter rows take at most 0.7 of the 256 MiB cache each (profiles/r05/
+    # chunk_share_sweep.txt); ensembles whose rows fit the cache (the 1M bench workload, the 1.25M config-4 shard) are not chunked
+    auto = EnsembleEngine.auto_chunk
+    assert auto(8_000_000, 6, 3, torch.float64) == 1_143_040 and auto(12_500_000, 6, 3, torch.float32) == 2_083_584
+    assert auto(1_000_000, 6, 3, torch.float64) == 0 == auto(1_250_000, 6, 3, torch.float64) == auto(1_700_000, 6, 3, torch.float64)
+    assert auto(1_800_000, 6, 3, torch.float64) == 900_096 and auto(2_400_000, 6, 3, torch.float64) == 1_200_128
+    for n, td, w in ((1_800_000, torch.float64, 8), (8_000_000, torch.float64, 8), (100_000_000, torch.float32, 4), (4_000_001, torch.float32, 4)):
+        c = auto(n, 6, 3, td)
+        k = -(-n // c)
+        assert c % 256 == 0 and c * w * 19 <= 0.7 * (256 << 20) + 256 * w * 19 and n - (k - 1) * c > c // 2      # even: no small ragged last chunk
     chunked.close()
     plain.close()
 
