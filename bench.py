@@ -856,14 +856,18 @@ def main():
         w = 8 if a.dtype == "f64" else 4
         resident = w * (eng.sum_pools + 2 + 3 * G + 2) * n_big
         big.run(0, 6)
-        sm = event_timed(big, lambda t0_, t1_: big.run(t0_, t1_, join=False), 0, n_s, 100, 1,
+        # five batches of 100 launches, the MEDIAN batch: one batch in five to ten carries a hiccup of 10-40 % at this size
+        # (profiles/r05/ab_variants.txt section 6), and a single batch made this figure look bimodal (0.70 / 0.80)
+        sm = event_timed(big, lambda t0_, t1_: big.run(t0_, t1_, join=False), 0, n_s, 100, 5,
                          lanes=big.per_step_stream_list()) / 100
+        sm_med = float(np.median(sm))
         Ab = big.bytes_per_member_step("per_step")
-        ach = Ab * n_big / float(sm.mean()) / 1e9
+        ach = Ab * n_big / sm_med / 1e9
         pools_c = (ctypes.c_int32 * G)(*big.pools)
         streamed = [bool(big.lib.fiveeq_rows_streamed(G, pools_c, n_, n_big, w)) for _, n_, _ in big.per_step_launches()]
         roofline["hbm_resident"] = {"members": n_big, "state_and_parameter_bytes": resident,
-                                    "x_infinity_cache": resident / (256 << 20), "avg_launch_us": float(sm.mean()) * 1e6,
+                                    "x_infinity_cache": resident / (256 << 20), "avg_launch_us": sm_med * 1e6,
+                                    "batch_us_min_median_max": [float(sm.min()) * 1e6, sm_med * 1e6, float(sm.max()) * 1e6],
                                     "achieved": ach, "frac": ach / HBM_PEAK_GBS, "chunk_major": False,
                                     "rows": "streamed (non-temporal)" if all(streamed) else "cached",
                                     "frac_of_best_copy": ach / best_copy_gbs,
