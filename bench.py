@@ -856,8 +856,8 @@ def main():
         w = 8 if a.dtype == "f64" else 4
         resident = w * (eng.sum_pools + 2 + 3 * G + 2) * n_big
         big.run(0, 6)
-        # five batches of 100 launches, the MEDIAN batch: one batch in five to ten carries a hiccup of 10-40 % at this size
-        # (profiles/r05/ab_variants.txt section 6), and a single batch made this figure look bimodal (0.70 / 0.80)
+        # five batches of 100 launches, the MEDIAN batch (single passes at this size carry a hiccup of 10-40 % now and then:
+        # profiles/r05/ab_variants.txt section 6)
         sm = event_timed(big, lambda t0_, t1_: big.run(t0_, t1_, join=False), 0, n_s, 100, 5,
                          lanes=big.per_step_stream_list()) / 100
         sm_med = float(np.median(sm))

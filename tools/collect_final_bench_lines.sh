@@ -21,8 +21,6 @@ timeout -k 10 300 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OU
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_small_multigas_f64_10k.csv $OUT/valu.json 750 $OUT/pmc_sqa_small3 > /dev/null
 cp $OUT/valu.json $R/profiles/valu.json
 cd $R
-python3 bench.py > $OUT/bench_config3.json 2> $OUT/bench_config3.err; echo bench1
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_config3_driver_call_20_steps.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --mode fused > $OUT/bench_config3_fused.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --mode graph > $OUT/bench_config3_graph.json 2>/dev/null; echo bench4
 python3 bench.py --no-cpu-baseline --workload config2 > $OUT/bench_config2_per_step.json 2>/dev/null
@@ -37,6 +35,9 @@ python3 bench.py --no-cpu-baseline --dtype f32 --mode fused > $OUT/bench_config3
 python3 bench.py --no-cpu-baseline --workload config5 --dtype f32 --mode fused --no-trajectory > $OUT/bench_config5_f32_fused_no_trajectory.json 2>/dev/null; echo bench13
 python3 bench.py --no-cpu-baseline --no-hbm-resident --workload config5 --dtype f32 --members 100000000 --no-trajectory > $OUT/bench_config5_whole_on_one_gpu_f32_per_step.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --no-hbm-resident --workload config5 --dtype f32 --members 100000000 --no-trajectory --mode fused > $OUT/bench_config5_whole_on_one_gpu_f32_fused.json 2>/dev/null; echo bench15
+# the default line last, right before its twin under rocprofv3
+python3 bench.py > $OUT/bench_config3.json 2> $OUT/bench_config3.err; echo bench1
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_config3_driver_call_20_steps.json 2>/dev/null
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-hbm-resident > $OUT/bench_config3_under_rocprof.json 2> $OUT/trace.err
 for k in kernel_stats domain_stats; do src=$(ls -t $OUT/trace/*/*_$k.csv 2>/dev/null | head -1); [ -n "$src" ] && cp "$src" $OUT/${k}_bench_config3.csv; done
