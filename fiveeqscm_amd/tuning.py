@@ -78,8 +78,6 @@ def _pair_time(lib, a, b, scratch, iters):
     """Wall time (s) of one busy launch on stream a and — b given — another on b, both behind the same start."""
     import ctypes
     import time
-
-    import torch
     a.synchronize()
     if b is not None:
         b.synchronize()
