@@ -196,3 +196,34 @@ def test_rccl_first_contact_on_one_gpu():
         p.join(timeout=120)
     assert p.exitcode == 0
     assert all(res.values()), res
+
+
+def test_the_sharded_example_job_on_three_ranks(tmp_path):
+    """example/run_sharded.py — a whole job as a user would launch it (torch.distributed.run, one rank per GPU; here three
+    ranks share the card and exchange over gloo): its CSV must hold the percentiles of ONE engine run over the whole ensemble,
+    bit for bit (the design and the summary do not depend on the world size)."""
+    import subprocess
+    import sys
+    from fiveeqscm_amd import emissions, params, scenario
+    from fiveeqscm_amd.engine import EnsembleEngine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "summary.csv"
+    N = 90_001
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "example", "run_sharded.py"), "--members", str(N), "--backend", "gloo",
+           "--years", "100,749", "--out", str(out)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                                                                                    OMP_NUM_THREADS="2"))
+    assert res.returncode == 0, res.stderr[-2000:]
+    years, cols = scenario.read_summary_csv(str(out))
+    assert years.tolist() == [1865.0, 2514.0] and cols["count"].tolist() == [float(N)] * 2
+    whole = params.sample_ensemble_shard(params.default_params("multigas"), N, device="cuda:0")
+    eng = EnsembleEngine(whole, N, emissions.rcp_like_emissions(750, 3), device="cuda:0", output_steps=[100, 749],
+                         store_concentrations=False)
+    eng.run(mode="fused")
+    want = eng.gather_summary([100, 749])
+    assert np.array_equal(cols["percentiles"], want["percentiles"].numpy())
+    np.testing.assert_allclose(cols["mean"], want["mean"].numpy(), rtol=1e-13)
