@@ -27,12 +27,18 @@ while time.time() < t_end:
     p = params.sample_ensemble(params.default_params(kind), N, seed=int(rng.integers(1, 1 << 30)))
     out_steps = None if rng.random() < 0.5 else sorted(set(int(x) for x in rng.integers(0, n_steps, size=int(rng.integers(1, 6)))))
     stats = bool(rng.random() < 0.5)
-    kw = dict(dtype=dt, device="cuda:0", output_steps=out_steps, collect_stats=stats)
+    hist = None
+    if rng.random() < 0.3:                                  # in-loop histograms of every step: modes 'fused', 'per_step', 'auto' only
+        lo_h = float(rng.uniform(-2.0, 0.5))
+        hist = (lo_h, lo_h + float(rng.uniform(0.5, 12.0)), int(rng.choice([1, 7, 512, 4096])))
+    kw = dict(dtype=dt, device="cuda:0", output_steps=out_steps, collect_stats=stats, hist=hist)
     ref = EnsembleEngine(p, N, E, per_step_streams=1, chunk_members=0, **kw)
     lib.fiveeq_set_row_policy(0)
     ref.run(mode="per_step")
     torch.cuda.synchronize()
-    names = ["R", "S"] + (["C", "T"] if ref.T is not None else []) + (["T_stats"] if stats else [])
+    names = ["R", "S"] + (["C", "T"] if ref.T is not None else []) + (["T_stats"] if stats else []) + (["T_hist"] if hist else [])
+    if hist and out_steps is None:                          # ... equal the histograms of the stored rows
+        assert torch.equal(ref.T_hist, ref.T_histogram(*hist)), ("T_hist vs stored rows", kind, N, str(dt), hist)
     want = {k: getattr(ref, k).clone() for k in names}
     if dt == torch.float64 and N <= 70002:
         o = c_oracle.run(E, p, N, n_threads=8)
@@ -52,9 +58,9 @@ while time.time() < t_end:
         t, plan = 0, []
         while t < n_steps:
             seg = int(rng.integers(1, n_steps - t + 1))
-            modes = ["per_step", "graph", "fused", "ksteps", "auto"] + (["small"] if eng.small_form() else [])
+            modes = ["per_step", "fused", "auto"] if hist else ["per_step", "graph", "fused", "ksteps", "auto"] + (["small"] if eng.small_form() else [])
             mode = str(rng.choice(modes))
-            if mode == "per_step" and rng.random() < 0.3 and seg <= 4:
+            if mode == "per_step" and rng.random() < 0.3 and seg <= 4 and not hist:
                 for tt in range(t, t + seg):
                     eng.step(tt)
                 plan.append(("step", seg))
@@ -71,7 +77,7 @@ while time.time() < t_end:
                 ok = torch.equal(got[..., 2:], want[k][..., 2:]) and torch.allclose(got[..., :2], want[k][..., :2], rtol=1e-12, atol=1e-300)
             else:
                 ok = torch.equal(got, want[k])
-            assert ok, (k, kind, N, str(dt), n_steps, out_steps, stats, policy, streams, chunk, plan)
+            assert ok, (k, kind, N, str(dt), n_steps, out_steps, stats, hist, policy, streams, chunk, plan)
         eng.close(); del eng
         n_runs += 1
     n_cases += 1
