@@ -51,32 +51,51 @@ class CheckpointMixin:
         """Restore a checkpoint (after `join()` if a run(..., join=False) is still outstanding).  One WITHOUT summaries
         (include_outputs=False) restores the state only: the accumulators of this engine (T_hist, per-step moments) are then
         cleared, because they describe a run this state is not from."""
-        if self._ps_unjoined:
-            self.join()
-        for name in ("R", "S") + (("cumE",) if self.cumE is not None else ()):
+        # VALIDATE everything first, then mutate: a checkpoint whose n_steps / n_bins / n_rows do not match raises with the
+        # engine exactly as it was (round 5 copied R, S and reset the masks before it looked at the accumulators' shapes)
+        state_names = ("R", "S") + (("cumE",) if self.cumE is not None else ())
+        if "T_stats" in state and self.collect_stats:
+            self._wave_stats()                                   # the checkpoint carries wave records: make room for them (no state touched)
+        staged = {}
+        for name in state_names + ("T_stats", "T_hist", "C", "T", "_step_sums"):
             dst = getattr(self, name)
-            src = np.asarray(state[name], dtype=np.float64)
+            if name in state_names and name not in state:
+                raise KeyError(f"checkpoint has no {name!r}")
+            if dst is None or name not in state:
+                continue
+            src = np.asarray(state[name], dtype=np.float64) if name in state_names else np.asarray(state[name])
             if src.shape != tuple(dst.shape):
                 raise ValueError(f"{name}: checkpoint shape {src.shape}, engine {tuple(dst.shape)}")
-            dst.copy_(torch.from_numpy(src).to(self.dtype))
-        self.t_next = int(state.get("t_next", 0))
+            if name == "T_hist" and src.dtype.kind not in "iu":
+                raise ValueError(f"T_hist: checkpoint dtype {src.dtype}, want integer counts")
+            if name != "T_hist" and src.dtype.kind not in "fiu":
+                raise ValueError(f"{name}: checkpoint dtype {src.dtype}, want numbers")
+            staged[name] = src
+        valid = None
+        if "_step_sums_valid" in state and self._step_sums is not None:
+            valid = np.asarray(state["_step_sums_valid"], dtype=bool)
+            if valid.shape != self._step_sums_valid.shape:
+                raise ValueError(f"_step_sums_valid: checkpoint shape {valid.shape}, engine {self._step_sums_valid.shape}")
+            if valid.any() and "_step_sums" not in staged and "T_stats" not in staged:
+                raise ValueError("checkpoint marks step moments valid but carries neither _step_sums nor T_stats")
+        t_next = int(state.get("t_next", 0))
+        if not 0 <= t_next <= self.n_steps:
+            raise ValueError(f"t_next={t_next} outside 0..{self.n_steps}")
+
+        if self._ps_unjoined:
+            self.join()
+        for name, src in staged.items():                         # the accumulators' contents BEFORE the masks that describe them
+            dst = getattr(self, name)
+            dst.copy_(torch.from_numpy(src).to(dst.dtype))
+        if self.T_hist is not None and "T_hist" not in staged:
+            self.T_hist.zero_()
+        self.t_next = t_next
         self._step_sums_valid[:] = False
         self._stats_have[:] = False
-        if "_step_sums_valid" in state and self._step_sums is not None:
+        if valid is not None:
             # the saver's own mask of the steps it had moments for: the only word on which records are moments (a saver that
             # began at t_begin > 0 holds zero-filled records before it)
-            self._step_sums_valid[:] = np.asarray(state["_step_sums_valid"], dtype=bool)
-            self._stats_have[:] = self._step_sums_valid
-        elif "T_stats" in state and self.collect_stats:        # a checkpoint from before the mask existed: raw wave records of
+            self._step_sums_valid[:] = valid & ("_step_sums" in staged)
+            self._stats_have[:] = valid
+        elif "T_stats" in staged:                              # a checkpoint from before the mask existed: raw wave records of
             self._stats_have[:self.t_next] = True              # a run from step 0
-        if self.T_hist is not None and "T_hist" not in state:
-            self.T_hist.zero_()
-        if "T_stats" in state:
-            self._wave_stats()                                   # the checkpoint carries wave records: make room for them
-        for name in ("T_stats", "T_hist", "C", "T", "_step_sums"):
-            dst = getattr(self, name)
-            if dst is not None and name in state:
-                src = np.asarray(state[name])
-                if src.shape != tuple(dst.shape):
-                    raise ValueError(f"{name}: checkpoint shape {src.shape}, engine {tuple(dst.shape)}")
-                dst.copy_(torch.from_numpy(src).to(dst.dtype))

@@ -481,9 +481,6 @@ const char* fiveeq_source_hash(void) { return FIVEEQ_SOURCE_HASH; }
 #define FIVEEQ_STR(x) FIVEEQ_STR2(x)
 const char* fiveeq_build_flags(void) {
     return ""
-#ifdef FIVEEQ_FUSED_TIMING
-           " FIVEEQ_FUSED_TIMING"
-#endif
 #ifdef FIVEEQ_STEP_WAVES
            " FIVEEQ_STEP_WAVES=" FIVEEQ_STR(FIVEEQ_STEP_WAVES)
 #endif
@@ -498,9 +495,6 @@ const char* fiveeq_build_flags(void) {
 #endif
 #if FIVEEQ_STEP_BLOCK != 64
            " FIVEEQ_STEP_BLOCK=" FIVEEQ_STR(FIVEEQ_STEP_BLOCK)
-#endif
-#ifdef FIVEEQ_BIN_RULE_F64
-           " FIVEEQ_BIN_RULE_F64"
 #endif
 #if FIVEEQ_FUSED_CHUNK != 125
            " FIVEEQ_FUSED_CHUNK=" FIVEEQ_STR(FIVEEQ_FUSED_CHUNK)

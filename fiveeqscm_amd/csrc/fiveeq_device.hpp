@@ -43,17 +43,6 @@
 #define FIVEEQ_FUSED_CHUNK 125    // drive-table steps staged into LDS per refill (fused kernel)
 #endif
 
-// Experiment hooks (wave / workgroup timestamps): empty in the product.  The code behind them lives in
-// tools/variants/fiveeq_timing_hooks.hpp and is compiled in only by -DFIVEEQ_FUSED_TIMING builds,
-// which fiveeq_build_flags() reports (tests/test_capi_cpu.py asserts the shipped library has none).
-#ifdef FIVEEQ_FUSED_TIMING
-#include "../../tools/variants/fiveeq_timing_hooks.hpp"
-#endif
-#ifndef FIVEEQ_HOOK_FUSED_BEGIN
-#define FIVEEQ_HOOK_FUSED_BEGIN
-#define FIVEEQ_HOOK_FUSED_END
-#endif
-
 namespace fiveeq {
 
 constexpr int MAX_GAS = 3;
@@ -467,7 +456,7 @@ __device__ __forceinline__ void stage_model(KModel<T>* dst) {
 }
 
 template <typename T>
-__device__ __forceinline__ void store_stream(T* p, T v) { *p = v; }   // plain stores (non-temporal: no gain, r01 A/B)
+__device__ __forceinline__ void store_stream(T* p, T v) { *p = v; }   // plain store (hfc_conc_kernel only; the step kernels' stored rows go through their NT policy)
 
 // ---------------------------------------------------------------------------------
 // Per-wave summary statistics of T for one step: (sum, sum of squares, min, max) over the wave's
@@ -774,9 +763,6 @@ template <> struct HistRule<double> {
 };
 template <> struct HistRule<float> {
     float scale, offset, top;
-#ifdef FIVEEQ_BIN_RULE_F64
-    double lo64, inv_w64;                     // A/B builds only
-#endif
 };
 __device__ __forceinline__ HistRule<double> make_rule(const double, const double lo, const double inv_w, const int n_bins) {
     return HistRule<double>{lo, inv_w, (double)(n_bins - 1)};
@@ -786,11 +772,7 @@ __device__ __forceinline__ HistRule<float> make_rule(const float, const double l
     // finite or infinite member always clamps into [0, n_bins - 1] and no index can leave the histogram
     const double big = 3.0e38;
     const float scale = (float)fmin(fmax(inv_w, -big), big), offset = (float)fmin(fmax(-lo * inv_w, -big), big);
-#ifdef FIVEEQ_BIN_RULE_F64
-    return HistRule<float>{scale, offset, (float)(n_bins - 1), lo, inv_w};
-#else
     return HistRule<float>{scale, offset, (float)(n_bins - 1)};
-#endif
 }
 __device__ __forceinline__ unsigned int hist_bin(const HistRule<double> r, const double v) {
     const double pos = (v - r.lo) * r.inv_w;
@@ -801,7 +783,8 @@ __device__ __forceinline__ unsigned int hist_bin_of_pos(const HistRule<float> r,
     const unsigned int b = (unsigned int)(int)__builtin_amdgcn_fmed3f(pos, 0.0f, r.top);       // v_med3_f32: the clamp in one op
     return v == v ? b : (unsigned int)BIN_NAN;
 }
-#ifndef FIVEEQ_BIN_RULE_F64
+// (rounds 2-3 binned fp32 rows by the fp64 formula — convert, subtract, multiply, clamp, truncate: ~10 quarter-rate instructions
+// per lane; the A/B against this one fp32 FMA is profiles/r04/ab_variants.txt, the knob is gone)
 __device__ __forceinline__ unsigned int hist_bin(const HistRule<float> r, const float v) {
     return hist_bin_of_pos(r, __builtin_fmaf(v, r.scale, r.offset), v);
 }
@@ -810,9 +793,6 @@ __device__ __forceinline__ unsigned int hist_bin2(const HistRule<float> r, const
     const float2v pos = __builtin_elementwise_fma(v, (float2v)r.scale, (float2v)r.offset);
     return hist_bin_of_pos(r, pos.x, v.x) | (hist_bin_of_pos(r, pos.y, v.y) << 16);
 }
-#else          // A/B builds only (tools/variants/bin_rule_f64.hpp): rounds 2-3's fp64 formula on fp32 rows
-#include "../../tools/variants/bin_rule_f64.hpp"
-#endif
 
 #ifdef FIVEEQ_STEP_WAVES
 #define FIVEEQ_STEP_ATTR __attribute__((amdgpu_waves_per_eu(FIVEEQ_STEP_WAVES, FIVEEQ_STEP_WAVES)))
@@ -955,7 +935,6 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     int ks = 0;                                                                      // steps parked in the tile
     const HistRule<T> rule = make_rule(T(0), hist_lo, hist_inv_w, n_bins);           // (BINS only)
 
-    FIVEEQ_HOOK_FUSED_BEGIN
     V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
     if constexpr (INV) {
 #pragma unroll
@@ -1019,7 +998,6 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
             }
         }
     }
-    FIVEEQ_HOOK_FUSED_END
     if (active) {
 #pragma unroll
         for (int k = 0; k < L::SP; ++k) store_lane(R + k * ld + m, Rv[k], full);

@@ -368,8 +368,15 @@ def _device_summary(rows, percentiles, dst, group, stats, local_sums=None, gmin=
         # one row with heavy ties would size the candidate buffer of EVERY row: summarise the rows in two halves (the decision
         # rests on the all-reduced histogram, so every rank takes it alike); the extrema and the member count are known
         h = K // 2
-        halves = [_device_summary(rows[a:b], percentiles, dst, group, None, gmin=lo_np[a:b], gmax=hi_np[a:b], n_total=n_tot,
-                                  want_moments=False, n_bins=n_bins)[1] for a, b in ((0, h), (h, K))]
+        half_stats = [None if stats is None else {} for _ in range(2)]
+        halves = [_device_summary(rows[a:b], percentiles, dst, group, st_h, gmin=lo_np[a:b], gmax=hi_np[a:b], n_total=n_tot,
+                                  want_moments=False, n_bins=n_bins)[1] for (a, b), st_h in zip(((0, h), (h, K)), half_stats)]
+        if stats is not None:
+            # what travelled is what the halves sent (each half all-reduces its own histogram again: counted too)
+            stats["split_rows"] = True
+            stats["bytes_to_root"] = sum(st_h["bytes_to_root"] for st_h in half_stats)
+            stats["allreduce_bytes"] += sum(st_h["allreduce_bytes"] for st_h in half_stats)
+            stats["bytes_to_root_per_rank"] = [sum(v) for v in zip(*(st_h["bytes_to_root_per_rank"] for st_h in half_stats))]
         out = None if halves[0] is None else np.concatenate(halves, axis=0)
         return mom, out
     cap = max(1, int(min(n_local, n_cand.max())))

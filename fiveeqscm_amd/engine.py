@@ -28,7 +28,8 @@ from . import _capi
 from .checkpoint import CheckpointMixin
 from .emissions import make_drive
 from .params import make_model, n_gas_of, pools_of
-from .tuning import _env_choice, _env_positive, calibrate, concurrent_side_streams  # noqa: F401  (calibrate: part of this module's interface)
+from .tuning import (_env_choice, _env_positive, calibrate, concurrent_side_streams,  # noqa: F401  (calibrate: part of this
+                     side_stream_report)                                               # module's interface)
 
 _DTYPES = {torch.float64: "f64", torch.float32: "f32"}
 INFINITY_CACHE_BYTES = 256 << 20     # MI355X die-level L3 (MI355X_MICROARCH.md); sizes the chunk-major schedule
@@ -221,13 +222,17 @@ class EnsembleEngine(CheckpointMixin):
         if small_lanes != "auto" and int(small_lanes) not in (1, 4):
             raise ValueError("small_lanes must be 'auto', 1 or 4")
         self.small_lanes = small_lanes if small_lanes == "auto" else int(small_lanes)
-        self._ps_unjoined = False           # run(..., join=False) left work on the side streams the caller's has not waited for
+        # run(..., join=False) left work nobody has waited for: the streams of THAT run ([its main, its side streams]) — join()
+        # waits for exactly these, whichever stream the consumer is on; None = nothing outstanding
+        self._ps_unjoined = None
         self._R0 = None if R0 is None else np.asarray(R0, dtype=np.float64).reshape(SP, N)
         self._S0 = None if S0 is None else np.asarray(S0, dtype=np.float64).reshape(2, N)
         self.t_next = 0                     # first step not yet run (bookkeeping for checkpoints)
         self.last_mode = None               # the mode the last run() used after resolving 'auto'
         self.reset_state()
         self._plans = {}
+        with torch.cuda.device(self.device):
+            self.probe_streams()            # construction is synchronous anyway: the one place the probe may clock streams
 
     @staticmethod
     def auto_chunk(n_members, sum_pools, n_gas, dtype, cache_bytes=INFINITY_CACHE_BYTES):
@@ -448,21 +453,51 @@ class EnsembleEngine(CheckpointMixin):
         n_streams = 1 + max(i for _, _, i in self.per_step_launches())
         if n_streams == 1:
             return [main]
-        # side streams that were PROBED to run beside `main` (tuning.concurrent_side_streams: a stream that shares main's
-        # hardware queue serialises the parts, +12 % per step); one probe per (device, main) and process, ~10 ms
+        # side streams PROBED to run beside `main` (a stream that shares main's hardware queue serialises the parts, +12 % per
+        # step): probed at construction / by probe_streams(), never here — an unprobed main gets plain streams (tuning.py)
         return [main] + concurrent_side_streams(self.lib, main, n_streams - 1)
 
     def join(self, stream=None):
-        """Make the caller's stream wait for everything run(..., join=False) enqueued on the side streams."""
-        streams = self.per_step_stream_list(stream)
-        for s in streams[1:]:
-            streams[0].wait_stream(s)
-        self._ps_unjoined = False
+        """Make `stream` (default: the current stream) wait for everything run(..., join=False) left outstanding — on the
+        streams THAT run used: its side streams and, when the consumer is another stream than the run's main, that main too."""
+        pending, self._ps_unjoined = self._ps_unjoined, None
+        if pending:
+            consumer = stream if stream is not None else torch.cuda.current_stream(self.device)
+            for s in pending:
+                if s.cuda_stream != consumer.cuda_stream:
+                    consumer.wait_stream(s)
+
+    def probe_streams(self, stream=None):
+        """Probe (tuning.concurrent_side_streams, probe=True) side streams for `stream` (default: the current one) so that the
+        two-stream schedules launched from it really overlap.  SYNCHRONISES that stream: call it where that is harmless — the
+        constructor does, for the stream current at construction; a caller that runs the engine on another stream of its own
+        calls this once before its first run().  Returns side_stream_report()."""
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
+        want = self._side_streams_wanted()
+        if want:
+            if self._ps_unjoined:
+                self.join(main)
+            concurrent_side_streams(self.lib, main, want, probe=True)
+        return self.side_stream_report(main)
+
+    def _side_streams_wanted(self):
+        n = max(i for _, _, i in self.per_step_launches())
+        if self.T_hist is not None and self.hist_pass_stream == "side":
+            n = max(n, 1)
+        return n
+
+    def side_stream_report(self, stream=None):
+        """{"wanted", "probed", "passed", "candidates_tried", "probe_enabled"} for the side streams runs on `stream` use."""
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
+        want = self._side_streams_wanted()
+        return {"wanted": want, **side_stream_report(main, want)}
 
     def _on_part_streams(self, stream, join, body):
         """Run body(streams) with the side streams ordered behind the caller's stream before it and (join=True) the caller's
         stream ordered behind them after it — the frame of every form that runs the parts of a chunk side by side."""
         streams = self.per_step_stream_list(stream)
+        if self._ps_unjoined and [s.cuda_stream for s in self._ps_unjoined] != [s.cuda_stream for s in streams]:
+            self.join(streams[0])                                # an unjoined run on OTHER streams: order this one behind it
         if not self._ps_unjoined:
             for s in streams[1:]:
                 s.wait_stream(streams[0])                        # the state may have been touched on the caller's stream
@@ -471,7 +506,7 @@ class EnsembleEngine(CheckpointMixin):
             if join:
                 for s in streams[1:]:
                     streams[0].wait_stream(s)
-            self._ps_unjoined = not join
+            self._ps_unjoined = None if join else list(streams)
         return rc
 
     def _per_step_schedule(self, t_begin, t_end, stream, join, block, launch):

@@ -3,6 +3,7 @@
 The figures themselves (HBM_STREAM_BYTES_PER_S, LAUNCH_BOUNDARY_S, ...) are attributes of fiveeqscm_amd.engine, where the
 schedules that use them live; `calibrate()` measures the two that depend on the box and writes them there."""
 import os
+import threading
 
 
 def _env_positive(name, default):
@@ -67,9 +68,17 @@ def calibrate(device="cuda:0", members=1_000_000, apply=True):
 # launch, the histogram pass beside the next fused chunk) then silently loses its overlap: the per-step form is 12 % slower
 # (4M fp64 members: 158 us per step instead of 141) for every fourth stream torch hands out (profiles/r05/side_stream_probe.txt).
 # So the side streams are PROBED: two launches of known duration (fiveeq_busy, one wave each) on the caller's stream and on the
-# candidate take the time of one when the streams are concurrent and of two when they are not.  The answer depends on the pair of
-# streams only: it is cached per (device, caller's stream) and shared by every engine of the process.
-_SIDE_STREAMS = {}
+# candidate take the time of one when the streams are concurrent and of two when they are not.
+#
+# WHEN (round 6): the probe synchronises both streams and clocks them on the wall, so it runs where the caller is synchronous
+# anyway — EnsembleEngine.__init__ (for the stream current at construction) and EnsembleEngine.probe_streams(stream) — never
+# inside run() / join() / a graph launch: those take what the cache holds for (device, caller's stream) and, for a stream nobody
+# probed, plain unprobed side streams (correctness never depends on the overlap).  The verdict is RECORDED with the streams
+# (`side_stream_report`): a probe that no candidate passed — several processes sharing the card, a profiler that serialises
+# kernels — is visible on the engine and in bench.py's line instead of silently giving the serialised form.  FIVEEQ_SIDE_STREAM_PROBE=0
+# skips probing altogether (counter-collection runs: no fiveeq_busy dispatches in the trace); a capturing stream is never probed.
+_SIDE_STREAMS = {}               # (device index, hipStream handle) -> {"main", "streams", "probed", "passed", "tried"}
+_SIDE_LOCK = threading.RLock()   # the C ABI is used from several host threads: the cache is theirs in common
 _PROBE_ITERS = 60_000            # ~0.2 ms per launch: far above the launch and synchronisation overheads around it
 _PROBE_CANDIDATES = 8
 
@@ -106,22 +115,65 @@ def streams_concurrent(lib, a, b, scratch=None):
     return two < 1.5 * one
 
 
-def concurrent_side_streams(lib, main, count):
-    """`count` HIP streams on main's device that run beside `main` AND beside each other, probed once per (device, main) and
-    shared by every caller in the process.  A candidate that fails the probe is dropped (torch recycles its pool of streams, so
-    nothing leaks); if no candidate passes within _PROBE_CANDIDATES tries the last one is taken as it is — correctness never
-    depends on the overlap."""
+def probe_enabled():
+    """FIVEEQ_SIDE_STREAM_PROBE=0 switches the probe off (plain side streams, recorded as unprobed)."""
+    return _env_choice("FIVEEQ_SIDE_STREAM_PROBE", "1", ("0", "1")) == "1"
+
+
+def _capturing(stream):
+    import torch
+    with torch.cuda.stream(stream):
+        return bool(torch.cuda.is_current_stream_capturing())
+
+
+def concurrent_side_streams(lib, main, count, probe=False):
+    """`count` HIP streams on main's device to run beside `main`, shared by every caller in the process (one entry per
+    (device, main)).
+
+    probe=False (run(), join(), graph launches): never synchronises — the cached streams, topped up with plain unprobed ones.
+    probe=True (engine construction, EnsembleEngine.probe_streams): entries that were never probed are (re)built from candidates
+    that pass `streams_concurrent` against main AND against each other; a candidate that fails is dropped (torch recycles its
+    pool of streams, so nothing leaks); if none of _PROBE_CANDIDATES passes, the last one is taken as it is and the entry records
+    passed=False.  Not probed at all: FIVEEQ_SIDE_STREAM_PROBE=0, a capturing `main`, an ExternalStream (its handle may be
+    destroyed and reused by the owner, so a verdict about it is not worth caching)."""
     import torch
     key = (main.device.index, main.cuda_stream)
-    have = _SIDE_STREAMS.setdefault(key, [])
-    if len(have) < count:
-        with torch.cuda.device(main.device):
-            scratch = torch.zeros(2, dtype=torch.float64, device=main.device)
-            while len(have) < count:
-                cand = None
-                for _ in range(_PROBE_CANDIDATES):
-                    cand = torch.cuda.Stream(device=main.device)
-                    if all(streams_concurrent(lib, s, cand, scratch) for s in [main] + have):
-                        break
-                have.append(cand)
-    return have[:count]
+    with _SIDE_LOCK:
+        ent = _SIDE_STREAMS.get(key)
+        if ent is None:
+            # `main` is kept: a torch-pooled stream object alive here keeps its handle from being handed to anyone else
+            ent = _SIDE_STREAMS[key] = {"main": main, "streams": [], "probed": False, "passed": [], "tried": 0}
+        may_probe = (probe and probe_enabled() and not isinstance(main, torch.cuda.ExternalStream) and not _capturing(main))
+        if may_probe and not (ent["probed"] and len(ent["streams"]) >= count):
+            with torch.cuda.device(main.device):
+                scratch = torch.zeros(2, dtype=torch.float64, device=main.device)
+                have = ent["streams"] if ent["probed"] else []
+                passed = ent["passed"] if ent["probed"] else []
+                while len(have) < count:
+                    cand, ok = None, False
+                    for _ in range(_PROBE_CANDIDATES):
+                        cand = torch.cuda.Stream(device=main.device)
+                        ent["tried"] += 1
+                        ok = all(streams_concurrent(lib, s, cand, scratch) for s in [main] + have)
+                        if ok:
+                            break
+                    have.append(cand)
+                    passed.append(bool(ok))
+                ent.update(streams=have, passed=passed, probed=True)
+        while len(ent["streams"]) < count:                         # unprobed top-up: no synchronisation, no verdict
+            with torch.cuda.device(main.device):
+                ent["streams"].append(torch.cuda.Stream(device=main.device))
+            ent["passed"].append(None)
+        return list(ent["streams"][:count])
+
+
+def side_stream_report(main, count=None):
+    """What the cache knows about main's side streams: {"probed", "passed" (True / False per stream, None = not probed),
+    "candidates_tried", "probe_enabled"} — on the engine as `side_stream_report()`, in bench.py's line as config.side_streams."""
+    with _SIDE_LOCK:
+        ent = _SIDE_STREAMS.get((main.device.index, main.cuda_stream))
+        if ent is None:
+            return {"probed": False, "passed": [], "candidates_tried": 0, "probe_enabled": probe_enabled()}
+        passed = list(ent["passed"] if count is None else ent["passed"][:count])
+        return {"probed": bool(ent["probed"]), "passed": passed, "candidates_tried": int(ent["tried"]),
+                "probe_enabled": probe_enabled()}

@@ -126,7 +126,7 @@ const char *fiveeq_last_error(void);
  * fiveeq_capi.hip, fiveeq_device.hpp, include/fiveeq.h — stamped by csrc/Makefile ("unstamped" otherwise).  A binding that
  * sits next to those sources recomputes it and refuses a library built from other text (fiveeqscm_amd/_capi.py). */
 const char *fiveeq_source_hash(void);
-/* new — the experiment knobs this library was compiled with (-DFIVEEQ_FUSED_TIMING, -DFIVEEQ_STEP_WAVES=..., non-default
+/* new — the experiment knobs this library was compiled with (-DFIVEEQ_STEP_WAVES=..., -DFIVEEQ_FUSED_CHUNK=..., non-default
  * block sizes ...), space-separated; "" for the product build. */
 const char *fiveeq_build_flags(void);
 /* new — sizeof(fiveeq_model) as the library was compiled, for binding self-checks */

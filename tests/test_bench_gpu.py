@@ -42,10 +42,22 @@ def test_default_mode_line_has_the_contract_keys():
     assert r["single_launch"]["frac"] == r["single_launch_frac"] and 0.0 < r["single_launch_frac"] < 1.2
     assert (r["concurrent_launches"] == 1) == (r["single_launch_avg_us"] == r["avg_launch_us"])
     # the scalars a reader needs come FIRST in the object (the driver's parser keeps the head of a nested object)
-    assert list(r)[:8] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_resident_frac", "single_launch_frac"]
+    assert list(r)[:9] == ["bound", "achieved", "peak", "unit", "frac", "regime", "traffic", "hbm_resident_frac", "single_launch_frac"]
+    # `frac` prices algorithmic bytes against the HBM PEAK: the regime beside it says whether those bytes cross HBM at all
+    # (300k members: 46 MB of rows live in the Infinity Cache; the beyond-the-cache leg carries its own label)
+    assert r["regime"].startswith("infinity-cache-resident (46 MB") and r["hbm_resident"]["regime"].startswith("hbm-streamed (")
     assert d["config"]["mode_resolved"] == "per_step" and len(d["config"]["devices"]) == 1
     dev0 = d["config"]["devices"][0]
     assert dev0["rank"] == 0 and dev0["device_index"] == 0 and dev0["name"] and len(dev0["pci_bus_id"].split(":")) == 3
+    # the rank's host thread was bound to its GPU's CPUs from sysfs before the GPU was touched, and the runtime's own PCI
+    # address confirmed the guess (or the report says why nothing was applied: a sandbox without the KFD topology)
+    cb = dev0["cpu_binding"]
+    assert cb["applied"] is True or cb.get("reason"), cb
+    if cb["applied"]:
+        assert dev0["cpus"] == cb["cpus"] and cb["n_cpus"] >= 1 and cb["pci_bus_id_runtime"] == dev0["pci_bus_id"]
+        assert cb["verified"] or cb.get("rebound_after_init")
+    ss = dev0["side_streams"]                                    # 300k members: one launch per step, no side stream wanted
+    assert ss["wanted"] == 0 and ss["probe_enabled"] is True
     assert len(d["timing"]["per_rank_ms_per_step"]) == 1 and abs(d["timing"]["per_rank_ms_per_step"][0] - d["ms_per_step"]) < 1e-9
     assert "workload" in d["config"] and "model" not in d["config"]
     c = d["cpu_baseline"]
@@ -140,6 +152,12 @@ def test_multi_rank_launch_prints_one_line_and_the_world_size_invariant_summary(
     devs = d["config"]["devices"]
     assert [x["rank"] for x in devs] == list(range(n)) and len({x["pid"] for x in devs}) == n
     assert all(x["name"] and x["device_index"] == x["local_rank"] % x["visible_devices"] for x in devs)
+    # every rank's host thread on its own CPUs: the ranks share the one card here, so they share its CPU list in disjoint slices
+    bound = [x["cpu_binding"] for x in devs if x["cpu_binding"]["applied"]]
+    if bound:
+        from fiveeqscm_amd.hostbind import parse_cpulist
+        sets = [set(parse_cpulist(x["cpus"])) for x in bound]
+        assert len(bound) == n and all(sets) and all(not (sets[i] & sets[j]) for i in range(n) for j in range(i)), [x["cpus"] for x in bound]
     t = d["timing"]
     assert len(t["per_rank_ms_per_step"]) == n == len(t["per_rank_host_enqueue_us"]) and min(t["per_rank_ms_per_step"]) > 0
     assert max(t["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.5 and max(t["per_rank_host_enqueue_us"]) <= t["host_enqueue_us_per_step"] * 1.0001

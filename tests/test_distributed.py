@@ -352,6 +352,26 @@ def _worker_passes(rank, world, port, n_total, q):
                 ok = ok and (world == 1 or 0 < st["bytes_to_root"])
             else:
                 ok = ok and s["percentiles"] is None and abs(float(s["mean"][0]) - full[0].astype(dt).astype(np.float64).mean()) < 1e-6
+        # the heavy-ties fallback (rows summarised in halves) must still account for what travelled (the caller's
+        # bytes_to_root / bytes_to_root_per_rank stayed 0 although candidates did travel)
+        from fiveeqscm_amd import distributed as D
+        saved, D.SELECT_CAND_BYTES = D.SELECT_CAND_BYTES, 2_000
+        try:
+            mine = torch.from_numpy(full[:, lo:hi])
+            st, st_whole = {}, {}
+            s = gather_summary(mine, percentiles=pct, stats=st)
+            D.SELECT_CAND_BYTES = saved
+            gather_summary(mine, percentiles=pct, stats=st_whole)
+            ok = ok and st.get("split_rows") is True and "split_rows" not in st_whole
+            ok = ok and len(st["bytes_to_root_per_rank"]) == world and sum(st["bytes_to_root_per_rank"]) == st["bytes_to_root"]
+            ok = ok and st["bytes_to_root_per_rank"][0] == 0 and st["allreduce_bytes"] > st_whole["allreduce_bytes"]
+            ok = ok and (world == 1 or (st["bytes_to_root"] > 0 and all(v > 0 for v in st["bytes_to_root_per_rank"][1:])))
+            # every half selects from its OWN rows' bins: together they send exactly what the unsplit summary sends
+            ok = ok and st["bytes_to_root"] == st_whole["bytes_to_root"]
+            if rank == 0:
+                ok = ok and np.array_equal(s["percentiles"].numpy(), np.percentile(full, pct, axis=1).T)
+        finally:
+            D.SELECT_CAND_BYTES = saved
         q.put(bool(ok))
         dist.barrier()
     finally:

@@ -10,6 +10,7 @@ C sits on a 278/720/270 pedestal, so the comparisons use |a-b| <= 1e-10 |b| + at
 atol = 1e-13 (K or ppm/ppb), far below any physical scale.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -553,6 +554,18 @@ def test_checkpoint_state_dict_roundtrip(gpu, tmp_path):
     assert torch.equal(bare.T[33:], whole.T[33:]) and torch.equal(bare.C[33:], whole.C[33:])
     with pytest.raises(ValueError):
         second.load_state_dict({"R": np.zeros((2, 2)), "S": np.zeros((2, N))})
+    # a checkpoint that does not fit is refused BEFORE anything is copied (R, S and the masks used to be overwritten
+    # before the accumulators' shapes were looked at): the engine keeps its state, its accumulators and its bookkeeping
+    before = {k: getattr(second, k).clone() for k in ("R", "S", "T_hist", "T_stats", "_step_sums")}
+    masks = (second._step_sums_valid.copy(), second._stats_have.copy(), second.t_next)
+    good = first.state_dict(include_outputs=True)
+    for bad in (dict(good, T_hist=good["T_hist"][:, :100]), dict(good, T=good["T"][:5]), dict(good, _step_sums=good["_step_sums"][:7]),
+                dict(good, T_hist=good["T_hist"].astype(np.float64)), dict(good, t_next=n_steps + 1),
+                dict(good, _step_sums_valid=good["_step_sums_valid"][:3]), {k: v for k, v in good.items() if k != "S"}):
+        with pytest.raises((ValueError, KeyError)):
+            second.load_state_dict(bad)
+        assert all(torch.equal(getattr(second, k), v) for k, v in before.items())
+        assert (second._step_sums_valid == masks[0]).all() and (second._stats_have == masks[1]).all() and second.t_next == masks[2]
 
 
 def test_reset_and_reload_clear_the_run_accumulators(gpu):
@@ -641,7 +654,7 @@ def test_random_models_and_scenarios_match_oracle(gpu):
     every compiled gas count: per-step, fused and small-ensemble paths against the NumPy oracle at 1e-10, and bit-identical
     among themselves (random forcing coefficients: the log, linear and square-root terms all on, or some of them exactly 0)."""
     rng = np.random.default_rng(2026)
-    worst = 0.0
+    worst, ran, loose, points, n_out, members = 0.0, 0, 0, 0, 0, 0
     for case in range(30):
         G = int(rng.integers(1, 4))
         pools = [int(rng.choice([1, 4])) for _ in range(G)]
@@ -677,13 +690,35 @@ def test_random_models_and_scenarios_match_oracle(gpu):
             if first is None:
                 first = (eng.C.clone(), eng.T.clone())
             assert torch.equal(eng.C, first[0]) and torch.equal(eng.T, first[1]), (case, mode, lanes, pools)    # one arithmetic
-            scale = np.maximum(np.abs(want["C"]), np.abs(want["C"] - np.asarray(base["PI_conc"])[None, :, None]).max())
-            errC = np.abs(eng.C.cpu().numpy() - want["C"]) / (RTOL * scale + ATOL)
-            errT = np.abs(eng.T.cpu().numpy() - want["T"]) / (RTOL * np.maximum(np.abs(want["T"]), np.abs(want["T"]).max())
-                                                                + ATOL)
-            worst = max(worst, float(errC.max()), float(errT.max()))
-            assert errC.max() <= 1.0 and errT.max() <= 1.0, (case, mode, pools, float(errC.max()), float(errT.max()))
-    assert worst > 0.0
+            # POINTWISE, the tolerance every other test uses: |got - want| <= 1e-10 |want| + 1e-13 at every stored value.  Two
+            # stated exceptions, both COUNTED so that a test that bounds everything loosely fails:
+            # (1) where the oracle's own trajectory passes through zero (|x| < 1e-3 of that member's largest |x|: random F_ext
+            #     makes T change sign) a relative bound is meaningless; there the bound is 1e-10 of the member's own scale;
+            # (2) members that leave the MODEL'S DOMAIN — a gas with a logarithmic or square-root forcing term driven to
+            #     C <= 0.02 C0 by the random negative emissions (draws 4, 18, 20, 26: 603 of 9530 members).  ln(C / C0) is singular
+            #     at 0 and the step guards it (log term := 0 for C <= 0, oracle/fiveeq_oracle.py step_forc): a discontinuity,
+            #     across which any rounding difference grows exponentially — the NumPy and the C oracle, the same algebra on the
+            #     same CPU, differ by 1.3x the bound on draw 18's member 58, and by <= 2e-4 of it on every in-domain member of
+            #     every draw.  Out-of-domain members are held to the draw-wide scale (round 5's bound for everything).
+            sing = (np.asarray(base["f"])[:, 0] != 0) | (np.asarray(base["f"])[:, 2] != 0)
+            outside = ((want["C"].min(axis=0) <= 0.02 * np.asarray(base["PI_conc"])[:, None]) & sing[:, None]).any(axis=0)      # [N]
+            for name in ("C", "T"):
+                w_ = want[name]
+                got = getattr(eng, name).cpu().numpy()
+                own = np.abs(w_).max(axis=0, keepdims=True)                  # per (gas,) member: its largest magnitude over time
+                near0 = np.abs(w_) < 1e-3 * own
+                scale = np.where(near0, own, np.abs(w_))
+                draw_wide = (np.abs(w_ - np.asarray(base["PI_conc"])[None, :, None]).max() if name == "C" else np.abs(w_).max())
+                scale = np.where(outside, np.maximum(scale, draw_wide), scale)
+                err = np.abs(got - w_) / (RTOL * scale + ATOL)
+                worst = max(worst, float(err.max()))
+                if mode == "per_step" and name == "T":
+                    loose, points = loose + int((near0 & ~outside).sum()), points + near0.size
+                    n_out, members = n_out + int(outside.sum()), members + outside.size
+                assert err.max() <= 1.0, (case, mode, pools, name, float(err.max()), np.unravel_index(err.argmax(), err.shape))
+        ran += 1
+    # every draw but the one the model itself cannot digest (draw 13 today) was held to the bound, nearly all of it pointwise
+    assert ran >= 27 and worst > 0.0 and loose <= 0.02 * points and n_out <= 0.08 * members, (ran, worst, loose, points, n_out, members)
 
 
 def test_minor_gas_forcing_equals_an_explicit_single_pool_gas(gpu):
@@ -1573,15 +1608,43 @@ def test_side_streams_are_probed_for_real_concurrency(gpu):
     from fiveeqscm_amd import _capi, tuning
     lib = _capi.load()
     main = torch.cuda.current_stream(gpu)
-    picked = tuning.concurrent_side_streams(lib, main, 2)
+    picked = tuning.concurrent_side_streams(lib, main, 2, probe=True)
+    rep = tuning.side_stream_report(main)
+    assert rep["probed"] and rep["passed"][:2] == [True, True] and rep["candidates_tried"] >= 2 and rep["probe_enabled"]
     assert len(picked) == 2 and len({main.cuda_stream, picked[0].cuda_stream, picked[1].cuda_stream}) == 3
     assert tuning.streams_concurrent(lib, main, picked[0]) and tuning.streams_concurrent(lib, main, picked[1])
     assert tuning.streams_concurrent(lib, picked[0], picked[1])
     assert not tuning.streams_concurrent(lib, main, main)
-    again = tuning.concurrent_side_streams(lib, main, 1)
+    again = tuning.concurrent_side_streams(lib, main, 1)                     # run()'s form: the cache, no probe, no synchronise
     assert again[0].cuda_stream == picked[0].cuda_stream
     other = torch.cuda.Stream()
-    mine = tuning.concurrent_side_streams(lib, other, 1)
+    # a stream nobody probed: run() gets plain side streams for it and never clocks anything (the probe used to
+    # synchronise the caller's stream inside an asynchronous API) ...
+    calls, real = [], tuning.streams_concurrent
+    tuning.streams_concurrent = lambda *a, **k: calls.append(a) or real(*a, **k)
+    try:
+        plain = tuning.concurrent_side_streams(lib, other, 1)
+        assert not calls and tuning.side_stream_report(other) == {"probed": False, "passed": [None], "candidates_tried": 0,
+                                                                  "probe_enabled": True}
+        assert plain[0].cuda_stream != other.cuda_stream
+        # ... nor does a capturing stream or FIVEEQ_SIDE_STREAM_PROBE=0, even when asked to probe
+        cap = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            tuning.concurrent_side_streams(lib, cap, 1, probe=True)
+        os.environ["FIVEEQ_SIDE_STREAM_PROBE"] = "0"
+        try:
+            off = torch.cuda.Stream()
+            tuning.concurrent_side_streams(lib, off, 1, probe=True)
+            assert tuning.side_stream_report(off)["probe_enabled"] is False and not tuning.side_stream_report(off)["probed"]
+        finally:
+            del os.environ["FIVEEQ_SIDE_STREAM_PROBE"]
+        assert not calls
+    finally:
+        tuning.streams_concurrent = real
+    # ... until somebody asks for the probe where a synchronise is harmless (EnsembleEngine.probe_streams)
+    mine = tuning.concurrent_side_streams(lib, other, 1, probe=True)
+    assert tuning.side_stream_report(other)["probed"] and tuning.side_stream_report(other)["passed"] == [True]
     assert mine[0].cuda_stream != other.cuda_stream and tuning.streams_concurrent(lib, other, mine[0])
     out = torch.zeros(1, dtype=torch.float64, device=gpu)
     assert lib.fiveeq_busy(10, ctypes.c_void_p(out.data_ptr()), None) == _capi.OK
@@ -1593,14 +1656,25 @@ def test_side_streams_are_probed_for_real_concurrency(gpu):
     probe, tuning.streams_concurrent = tuning.streams_concurrent, lambda *a, **k: False
     try:
         lonely = torch.cuda.Stream()
-        got = tuning.concurrent_side_streams(lib, lonely, 1)
+        got = tuning.concurrent_side_streams(lib, lonely, 1, probe=True)
         assert len(got) == 1 and got[0].cuda_stream != lonely.cuda_stream
+        failed = tuning.side_stream_report(lonely)                # ... and the failed probe is on record, not silent
+        assert failed["probed"] and failed["passed"] == [False] and failed["candidates_tried"] == tuning._PROBE_CANDIDATES
     finally:
         tuning.streams_concurrent = probe
     # and the engine uses them
     eng = _engine(prm.sample_ensemble(prm.default_params("multigas"), 4096), 4096, emi.rcp_like_emissions(20, 3), per_step_streams=2)
     assert [s.cuda_stream for s in eng.per_step_stream_list()] == [main.cuda_stream, picked[0].cuda_stream]
+    assert eng.side_stream_report() == {"wanted": 1, "probed": True, "passed": [True], "probe_enabled": True,
+                                        "candidates_tried": tuning.side_stream_report(main)["candidates_tried"]}
     eng.close()
+    # the cache is shared by host threads (the C ABI advertises multi-threaded use): eight threads asking at once get one answer
+    import threading
+    shared, seen = torch.cuda.Stream(), []
+    ths = [threading.Thread(target=lambda: seen.append(tuple(s.cuda_stream for s in tuning.concurrent_side_streams(lib, shared, 2))))
+           for _ in range(8)]
+    [t.start() for t in ths], [t.join() for t in ths]
+    assert len(set(seen)) == 1 and len(seen) == 8
 
 
 def test_calibrate_measures_the_box_dependent_constants(gpu):
@@ -1752,6 +1826,54 @@ def test_step_and_the_readers_join_an_unjoined_run(gpu):
     for t in range(6):
         a.step(t)
     assert not a._step_sums_valid[5] and torch.equal(a.stats_sums(0, 6), b.stats_sums(0, 6))
+    a.close(), b.close()
+
+
+def test_a_reader_on_another_stream_joins_the_streams_of_the_unjoined_run(gpu):
+    """run(..., stream=s1, join=False) leaves work on s1 AND on s1's side streams; a reader that runs on
+    the default stream (stats_sums, reset_state, load_state_dict, a later run on another main) must wait for exactly THOSE
+    streams — round 5 re-derived the side streams from the reader's stream and waited for the wrong ones, a silent race.  The
+    engine now remembers the stream list of the unjoined run.  A long busy kernel in front of the run on s1 makes the race wide
+    enough to see: without the join the reader would see zero state."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    N, n_steps = 600_000, 30
+    p = prm.sample_ensemble_shard(prm.default_params("multigas"), N, device="cuda:0")
+    E = emi.rcp_like_emissions(n_steps, 3)
+    b = _engine(p, N, E, collect_stats=True, per_step_streams=1)
+    b.run()
+    torch.cuda.synchronize()
+    want = b.stats_sums()
+    a = _engine(p, N, E, collect_stats=True, per_step_streams=2)
+    s1 = torch.cuda.Stream()
+    a.probe_streams(s1)
+    assert a.side_stream_report(s1)["probed"]
+    scratch = torch.zeros(1, dtype=torch.float64, device=gpu)
+    default = torch.cuda.current_stream(gpu)
+    for reader in ("stats_sums", "run_on_default", "state_dict_roundtrip", "reset_state"):
+        a.reset_state()
+        torch.cuda.synchronize()
+        s1.wait_stream(default)
+        assert lib.fiveeq_busy(3_000_000, ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(s1.cuda_stream)) == _capi.OK   # ~10 ms
+        a.run(0, n_steps if reader != "run_on_default" else 20, stream=s1, join=False)
+        assert a._ps_unjoined and [s.cuda_stream for s in a._ps_unjoined] == [s.cuda_stream for s in a.per_step_stream_list(s1)]
+        if reader == "stats_sums":
+            got = a.stats_sums()                                  # on the DEFAULT stream
+            assert a._ps_unjoined is None and torch.equal(got, want)
+        elif reader == "run_on_default":
+            a.run(20, n_steps)                                    # another main: ordered behind s1 and s1's side stream
+            torch.cuda.synchronize()
+            for name in ("C", "T", "R", "S"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), name
+        elif reader == "state_dict_roundtrip":
+            sd = b.state_dict()
+            a.load_state_dict(sd)                                 # must not be overwritten by the late kernels of the unjoined run
+            torch.cuda.synchronize()
+            assert torch.equal(a.R, b.R) and torch.equal(a.S, b.S) and a._ps_unjoined is None
+        else:
+            a.reset_state()
+            torch.cuda.synchronize()
+            assert int(a.R.abs().sum()) == 0 and int(a.S.abs().sum()) == 0
     a.close(), b.close()
 
 
