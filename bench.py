@@ -88,6 +88,8 @@ def parse():
                          "--host-share-limit (default: measure and report it, keep the per-step form)")
     ap.add_argument("--k-steps", type=int, default=0, help="steps per launch for --mode ksteps (0: the engine's choice)")
     ap.add_argument("--no-trajectory", action="store_true", help="do not store C/T rows (drops G+1 writes from A)")
+    ap.add_argument("--compensated", action="store_true",
+                    help="--dtype f32 --mode fused|ksteps only: the compensated fp32 form of the time-fused kernel (include/fiveeq.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the beyond-Infinity-Cache roofline leg")
     ap.add_argument("--hbm-resident-members", type=int, default=8_000_000)
@@ -166,7 +168,7 @@ def main():
     n_local = hi - lo
     p = params.sample_ensemble_shard(params.default_params(kind), n_total, lo, hi, device=dev, dtype=dtype)
     E = emissions.rcp_like_emissions(N_SCEN, G)
-    eng = EnsembleEngine(p, n_local, E, dtype=dtype, device=dev, store_trajectory=not a.no_trajectory)
+    eng = EnsembleEngine(p, n_local, E, dtype=dtype, device=dev, store_trajectory=not a.no_trajectory, compensated=a.compensated)
     torch.cuda.synchronize(dev)
     setup_s = time.perf_counter() - t_setup
 
@@ -341,7 +343,7 @@ def main():
                    "gases": G, "pools": eng.pools, "scenario_steps": N_SCEN, "mode": a.mode, "mode_resolved": mode_run,
                    "mode_requested": mode_requested or "default",
                    "steps_per_launch": (roofline.get("steps_per_launch", 1)),
-                   "trajectory_stored": eng.C is not None, "parallelism": f"member-shard x{world}",
+                   "trajectory_stored": eng.C is not None, "compensated_fp32": bool(a.compensated), "parallelism": f"member-shard x{world}",
                    "chunk_members": eng.chunk_members,
                    "collective_backend": "rccl" if backend == "nccl" else backend,
                    "control_plane": None if dist is None else "gloo over 127.0.0.1 (barriers, MAX of the clocked times)",

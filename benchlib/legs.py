@@ -284,6 +284,8 @@ def fused_roofline(eng, a, mode_run, k_steps, n_local):
                             "by the instructions ONE wave issues per step (valu_issue.valu_wave_instr_per_wave_step), not by the "
                             "chip's VALU peak: frac prices the waves that exist against all 1024 SIMDs at nominal issue.")
     kkey = (f"small:{vtag}:{pools3}:{lpm}" if kname == "small_kernel" else f"fused:{vtag}:{pools3}")
+    if eng.compensated:                                     # its own instruction stream: no committed SQ-counter pass under this key
+        roofline["kernel"], kkey = kernel_name.replace(">", ",false,false,true> (compensated fp32)"), kkey + ":comp"
     return roofline, k_avg, kkey, members_per_wave
 
 

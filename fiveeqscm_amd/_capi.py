@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FIVEEQ_LIB_PATH selects another build of the same library (e.g. the host-sanitizer build of tools/sanitize_host.sh)
 LIB_PATH = os.environ.get("FIVEEQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libfiveeq_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_GAS = 3
 MAX_POOLS = 4
 N_BOX = 2
@@ -95,6 +95,7 @@ SIGNATURES = {
     "fiveeq_run_ksteps_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
     "fiveeq_run_small_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
     "fiveeq_run_small_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
+    "fiveeq_run_fused_comp_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _i32, _p]),
     "fiveeq_small_lanes": (_i32, [_i32, ctypes.POINTER(_i32)]),
     "fiveeq_set_f32_packing": (ctypes.c_int, [ctypes.c_int]),
     "fiveeq_set_row_policy": (ctypes.c_int, [_i32]),

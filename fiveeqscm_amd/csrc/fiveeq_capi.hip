@@ -238,7 +238,7 @@ int launch_step(const RunArgs<T>& a, int t, hipStream_t st, const BinRing& br = 
     return FIVEEQ_OK;
 }
 
-template <typename T, bool INV, bool BINS = false>
+template <typename T, bool INV, bool BINS = false, bool COMP = false>
 int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream_t st, const BinRing& br = BinRing()) {
     using P = typename LaneOf<T>::Packed;
     constexpr bool HAS_PACKED = !INV && !std::is_same<P, T>::value;     // the inverse form has no packed instantiation
@@ -252,13 +252,13 @@ int launch_fused(const RunArgs<T>& a, int t_begin, int t_end, T* cumE, hipStream
     case (p0) * 100 + (p1) * 10 + (p2):                                                                \
         if constexpr (HAS_PACKED) {                                                                    \
             if (packed) {                                                                              \
-                hipLaunchKernelGGL((fused_kernel<P, p0, p1, p2, false, BINS>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km,  \
+                hipLaunchKernelGGL((fused_kernel<P, p0, p1, p2, false, BINS, COMP>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km,  \
                                    a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj,        \
                                    a.T_traj, a.n_rows, a.stats, br.ring, br.ring_rows, br.lo, br.inv_w, br.n_bins);         \
                 break;                                                                                 \
             }                                                                                          \
         }                                                                                              \
-        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV, BINS>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km, a.drive,   \
+        hipLaunchKernelGGL((fused_kernel<T, p0, p1, p2, INV, BINS, COMP>), grid, block, FIVEEQ_FUSED_DYN_LDS, st, a.km, a.drive,   \
                            a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, cumE, a.C_traj, a.T_traj, a.n_rows,    \
                            a.stats, br.ring, br.ring_rows, br.lo, br.inv_w, br.n_bins);                \
         break;
@@ -365,6 +365,37 @@ int run_ksteps(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int
     for (int t = t_begin; t < t_end; t += k_steps)
         if (int rc = launch_fused<T, false>(a, t, t + k_steps < t_end ? t + k_steps : t_end, nullptr, (hipStream_t)stream))
             return rc;
+    return FIVEEQ_OK;
+}
+
+// ---- the compensated fp32 form: the fused kernel <.., COMP = true> over spans of k_steps, with or without the bin ring ----
+int run_fused_comp(const fiveeq_model* m, int64_t n, int64_t ld, const float* drive, int32_t n_steps, int32_t t_begin,
+                   int32_t t_end, const float* r, const float* q, float* R, float* S, float* C_traj, float* T_traj, int n_rows,
+                   double* stats, int32_t k_steps, double lo, double hi, int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows,
+                   void* stream) {
+    RunArgs<float> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
+    if (k_steps < 1) return fail(FIVEEQ_E_INVALID, "k_steps=%d must be >= 1", k_steps);
+    BinRing br;
+    if (bin_ring) {
+        if (n_bins < 1 || n_bins > HIST_MAX_BINS) return fail(FIVEEQ_E_INVALID, "n_bins=%d outside 1..%d", n_bins, HIST_MAX_BINS);
+        if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) return fail(FIVEEQ_E_INVALID, "need finite lo < hi");
+        if (ring_rows < 1) return fail(FIVEEQ_E_INVALID, "ring_rows=%d must be >= 1", ring_rows);
+        if (((uintptr_t)bin_ring) & 1) return fail(FIVEEQ_E_INVALID, "bin_ring must be 2-byte aligned");
+        br.ring = bin_ring;
+        br.ring_rows = ring_rows;
+        br.lo = lo;
+        br.inv_w = (double)n_bins / (hi - lo);
+        br.n_bins = n_bins;
+    }
+    if (t_begin == t_end) return FIVEEQ_OK;
+    if (k_steps > t_end - t_begin) k_steps = t_end - t_begin;
+    for (int t = t_begin; t < t_end; t += k_steps) {
+        const int t1 = t + k_steps < t_end ? t + k_steps : t_end;
+        const int rc = bin_ring ? launch_fused<float, false, true, true>(a, t, t1, nullptr, (hipStream_t)stream, br)
+                                : launch_fused<float, false, false, true>(a, t, t1, nullptr, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     return FIVEEQ_OK;
 }
 
@@ -620,6 +651,13 @@ int fiveeq_run_ksteps_f32(const fiveeq_model* model, int64_t n_members, int64_t 
                           void* stream) {
     return run_ksteps<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows,
                              T_stats, k_steps, stream);
+}
+int fiveeq_run_fused_comp_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive, int32_t n_steps,
+                              int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R, float* S, float* C_traj,
+                              float* T_traj, int32_t n_rows, double* T_stats, int32_t k_steps, double lo, double hi,
+                              int32_t n_bins, uint16_t* bin_ring, int32_t ring_rows, void* stream) {
+    return run_fused_comp(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
+                          k_steps, lo, hi, n_bins, bin_ring, ring_rows, stream);
 }
 int fiveeq_run_small_f64(const fiveeq_model* model, int64_t n_members, int64_t ld, const double* drive,
                          int32_t n_steps, int32_t t_begin, int32_t t_end, const double* r, const double* q, double* R,

@@ -346,12 +346,26 @@ __device__ __forceinline__ float2v fe_sqrt(float2v x) {
 // ---------------------------------------------------------------------------------
 // V is the lane value type (double, float, or float2v = two members per lane); S its scalar type: the shared model and
 // the drive record are S, everything per member is V.
-template <typename V, typename L, int g, bool INV>
+//
+// COMP = true is the COMPENSATED fp32 form (round 6; opt-in, register-resident kernels only — fiveeq_run_fused_comp_f32):
+//   * every POOL carries a second word (Rlo): the rounding error of its own update, fed back into the next one —
+//     y = fma(em1, x, lo); t = R + y; lo = y - (t - R); R = t (Kahan's summation with the product fused into the first add);
+//     three more instructions per pool and step, no HBM bytes (the words live and die in registers).  The thermal boxes are NOT
+//     compensated: with the forcing below their rounding is 4e-7 of T, and their six instructions were 2.5 % of the kernel;
+//   * the forcing is computed from the EXCESS sumN = C - C0 instead of from the rounded C: ln(C/C0) = log1p(x), x = sumN / C0, as
+//     ln(u) + (x - (u - 1)) with u = fl(1 + x) (the correction's own 1/u is dropped: it matters only where u ~ 1, where it is 1),
+//     and sqrt C - sqrt C0 = sumN / (sqrt C + sqrt C0).  In fp32 the default form loses the small excess of the first decades to
+//     the rounding of C itself (ulp(278 ppm) = 3e-5 ppm against an excess of 1e-2 ppm: a forcing good to 1e-3 relative) — that,
+//     not the state, is what bounds T in fp32.
+// Against 50-digit arithmetic over the 24 golden members: C 2.9e-6 -> 1.4e-7, T 1.7e-5 -> 7e-7 (profiles/r06/fp32_compensated.txt).
+// It is its own arithmetic: NOT bit-identical to the default forms, and the per-step kernels (state in HBM) do not have it.
+template <typename V, typename L, int g, bool INV, bool COMP = false>
 __device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, const KGas<typename Lane<V>::S>& kg,
                                       const typename Lane<V>::S* __restrict__ drv, const V (&rr)[3 * L::G], const V T_old,
-                                      V (&R)[L::SP], V (&out)[L::G], V (&cum)[L::G]) {
+                                      V (&R)[L::SP], V (&out)[L::G], V (&cum)[L::G], V (&Rlo)[L::SP]) {
     using S = typename Lane<V>::S;
     static_assert(!INV || Lane<V>::W == 1, "the concentration-driven form has no packed instantiation");
+    static_assert(!COMP || (!INV && sizeof(S) == 4), "the compensated form is an fp32 form of the emission-driven step");
     constexpr int P = L::pools(g);
     constexpr int o = L::off(g);
     // --- alpha_val -----------------------------------------------------------------
@@ -392,7 +406,14 @@ __device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, con
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const V Ri = R[o + i];
-        const V Rn = fe_fma(em1[i], fma3<V>(-kg.atc[i], Ea, Ri), Ri);     // R + em1 (R - a tau c E alpha)
+        V Rn;
+        if constexpr (COMP) {
+            const V y = fe_fma(em1[i], fma3<V>(-kg.atc[i], Ea, Ri), Rlo[o + i]);     // the increment plus what earlier sums dropped
+            Rn = Ri + y;
+            Rlo[o + i] = y - (Rn - Ri);                                            // what THIS sum dropped
+        } else {
+            Rn = fe_fma(em1[i], fma3<V>(-kg.atc[i], Ea, Ri), Ri);         // R + em1 (R - a tau c E alpha)
+        }
         R[o + i] = Rn;
         sumN += Rn;
     }
@@ -401,7 +422,19 @@ __device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, con
     // --- step_forc (terms whose coefficient is zero are skipped: wave-uniform branch) ---
     const auto pos = fe_gt0(Cg);
     V Fg = kg.f2 * (Cg - kg.C0);
-    if constexpr (Lane<V>::W == 1) {
+    if constexpr (COMP) {
+        Fg = kg.f2 * sumN;
+        if (kg.f1 != S(0)) {
+            const V x = sumN * kg.inv_C0;                                          // C / C0 - 1, to the precision of the excess
+            const V u = fe_sel(pos, (V)S(1) + x, (V)S(1));
+            const V lg = fe_log(u) + (x - (u - (V)S(1)));                          // log1p(x)
+            Fg = fe_sel(pos, fma3<V>(kg.f1, lg, Fg), Fg);
+        }
+        if (kg.f3 != S(0)) {
+            const V den = fe_sqrt(fe_sel(pos, Cg, (V)S(1))) + kg.sqrtC0;
+            Fg = fma3<V>(kg.f3, fe_sel(pos, sumN * fe_rcp(den), (V)(-kg.sqrtC0)), Fg);
+        }
+    } else if constexpr (Lane<V>::W == 1) {
         if (kg.f1 != S(0)) Fg = pos ? fe_fma(kg.f1, fe_log(pos ? Cg * kg.inv_C0 : S(1)), Fg) : Fg;
         if (kg.f3 != S(0)) Fg = fe_fma(kg.f3, (pos ? fe_sqrt(pos ? Cg : S(1)) : S(0)) - kg.sqrtC0, Fg);
     } else {
@@ -411,29 +444,37 @@ __device__ __forceinline__ V gas_step(const KModel<typename Lane<V>::S>& km, con
     return Fg;
 }
 
-template <typename V, typename L, bool INV = false>
+template <typename V, typename L, bool INV, bool COMP>
 __device__ __forceinline__ void member_step(const KModel<typename Lane<V>::S>& km, const typename Lane<V>::S* __restrict__ drv,
                                             const V (&rr)[3 * L::G], const V (&qq)[2],
-                                            V (&R)[L::SP], V (&S)[2], V (&out)[L::G], V& Tnew, V (&cum)[L::G]) {
+                                            V (&R)[L::SP], V (&S)[2], V (&out)[L::G], V& Tnew, V (&cum)[L::G],
+                                            V (&Rlo)[L::SP]) {
     const V T_old = S[0] + S[1];
     V F = (V)drv[6];
     // compiler-only barriers: keep each gas's LDS constant reads inside that gas's code instead of all
     // ~45 being hoisted to the kernel top (VGPR pressure) or out of the fused time loop.  (Issuing gas
     // g+1's reads before gas g's arithmetic was tried: +-1 %, 133 VGPRs; not kept.)
     asm volatile("" ::: "memory");
-    F += gas_step<V, L, 0, INV>(km, km.gas[0], drv, rr, T_old, R, out, cum);
+    F += gas_step<V, L, 0, INV, COMP>(km, km.gas[0], drv, rr, T_old, R, out, cum, Rlo);
     if constexpr (L::G > 1) {
         asm volatile("" ::: "memory");
-        F += gas_step<V, L, 1, INV>(km, km.gas[1], drv, rr, T_old, R, out, cum);
+        F += gas_step<V, L, 1, INV, COMP>(km, km.gas[1], drv, rr, T_old, R, out, cum, Rlo);
     }
     if constexpr (L::G > 2) {
         asm volatile("" ::: "memory");
-        F += gas_step<V, L, 2, INV>(km, km.gas[2], drv, rr, T_old, R, out, cum);
+        F += gas_step<V, L, 2, INV, COMP>(km, km.gas[2], drv, rr, T_old, R, out, cum, Rlo);
     }
     // --- step_temp: S + em1_d (S - q F) ------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 2; ++j) S[j] = fma3<V>(km.em1_d[j], fe_fma(-qq[j], F, S[j]), S[j]);
     Tnew = S[0] + S[1];
+}
+template <typename V, typename L, bool INV = false>
+__device__ __forceinline__ void member_step(const KModel<typename Lane<V>::S>& km, const typename Lane<V>::S* __restrict__ drv,
+                                            const V (&rr)[3 * L::G], const V (&qq)[2],
+                                            V (&R)[L::SP], V (&S)[2], V (&out)[L::G], V& Tnew, V (&cum)[L::G]) {
+    V no_Rlo[L::SP];                                     // never touched: COMP = false
+    member_step<V, L, INV, false>(km, drv, rr, qq, R, S, out, Tnew, cum, no_Rlo);
 }
 template <typename V, typename L>
 __device__ __forceinline__ void member_step(const KModel<typename Lane<V>::S>& km, const typename Lane<V>::S* __restrict__ drv,
@@ -901,7 +942,7 @@ __global__ __launch_bounds__(FIVEEQ_STEP_BLOCK) FIVEEQ_STEP_ATTR void step_kerne
 // INV = true: concentration-driven form.  drive[t][0..2] are target concentrations, cumE [G][ld] is
 // per-member cumulative-emission state (in/out), and C_traj receives the DIAGNOSED EMISSIONS.
 // (112 VGPRs at fp64 4+1+1 = 4 waves/SIMD; launch-bounds hints for 5 or 6 waves spill: -3 % / -16 %.)
-template <typename V, int P0, int P1, int P2, bool INV, bool BINS = false>
+template <typename V, int P0, int P1, int P2, bool INV, bool BINS = false, bool COMP = false>
 __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const KModel<typename Lane<V>::S> km, const typename Lane<V>::S* __restrict__ drive, const int n_steps,
     const int t_begin, const int t_end, const int64_t n, const int64_t ld,
@@ -936,6 +977,11 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
     const HistRule<T> rule = make_rule(T(0), hist_lo, hist_inv_w, n_bins);           // (BINS only)
 
     V rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn, cum[L::G];
+    V Rlo[L::SP];                                         // COMP: the compensation words (zero at launch: they do not cross HBM)
+    if constexpr (COMP) {
+#pragma unroll
+        for (int k = 0; k < L::SP; ++k) Rlo[k] = (V)T(0);
+    }
     if constexpr (INV) {
 #pragma unroll
         for (int g = 0; g < L::G; ++g) cum[g] = cumE[g * ld + mm];
@@ -957,7 +1003,7 @@ __global__ __launch_bounds__(FIVEEQ_BLOCK) void fused_kernel(
         __syncthreads();
         for (int k = 0; k < nt; ++k) {
             const T* d = &drv[k * DRIVE_STRIDE];
-            member_step<V, L, INV>(kmr, d, rr, qq, Rv, Sv, Cv, Tn, cum);
+            member_step<V, L, INV, COMP>(kmr, d, rr, qq, Rv, Sv, Cv, Tn, cum, Rlo);
             // the output row is wave-uniform: read it once into an SGPR so that the row test is a
             // scalar branch and the row offsets are scalar arithmetic, not 64-bit VALU per lane
             const int row = __builtin_amdgcn_readfirstlane((int)d[7]);

@@ -88,8 +88,8 @@ class EnsembleEngine(CheckpointMixin):
     def __init__(self, params, n_members, emissions, *, F_ext=None, dt=1.0, dtype=torch.float64,
                  device=None, store_trajectory=True, output_steps=None, store_concentrations=True,
                  collect_stats=False, hist=None, hist_ring_steps="auto", concentration_driven=False,
-                 chunk_members="auto", per_step_streams="auto", fused_span="auto", small_lanes="auto", R0=None,
-                 S0=None, lib_path=None):
+                 chunk_members="auto", per_step_streams="auto", fused_span="auto", small_lanes="auto", compensated=False,
+                 R0=None, S0=None, lib_path=None):
         """store_trajectory / output_steps: True stores C, T of every step; a list of step indices
         stores only those (rows in increasing step order, see `out_steps`); False stores nothing.
         store_concentrations=False keeps only the T rows (a 100M-member fp32 run then stores 4 B instead
@@ -123,6 +123,11 @@ class EnsembleEngine(CheckpointMixin):
         long tail; relaunching the same kernel resets the ages (the state crosses HBM once per span: nothing at 128 steps).
         "auto": FUSED_SPAN_STEPS when the ensemble is between FUSED_SPAN_MIN_ROUNDS and FUSED_SPAN_MAX_ROUNDS rounds of resident
         waves, else one launch (profiles/r03/relaunch_sweep.txt).  Bit-identical either way.
+        compensated (fp32 only, opt-in): modes 'fused' / 'ksteps' run the COMPENSATED form of the time-fused kernel
+        (include/fiveeq.h, fiveeq_run_fused_comp_f32): every pool carries the rounding error of its own update in a second
+        register word (no HBM bytes) and the forcing is computed from the excess C - C0 — worst error against 50-digit
+        arithmetic C 2.9e-6 -> 1.8e-7, T 1.7e-5 -> 7e-7.  Its own arithmetic: not bit-identical to the default forms; the modes
+        that keep the state in HBM between launches ('per_step', 'graph') and the small-ensemble kernels refuse it.
         small_lanes: mode='small' (no in-loop histograms): lanes per member, 4 (a lone 4-pool gas: one pool per lane of a
         quad), 1 (any layout), or "auto" = 4 where the layout has it and every quad wave gets a SIMD of its own, else 1."""
         if dtype not in _DTYPES:
@@ -153,6 +158,9 @@ class EnsembleEngine(CheckpointMixin):
         if not store_trajectory:
             output_steps = []
         self.concentration_driven = bool(concentration_driven)
+        self.compensated = bool(compensated)
+        if self.compensated and (dtype != torch.float32 or self.concentration_driven):
+            raise ValueError("compensated=True is an fp32 form of the emission-driven step (fp64 does not need it)")
         drive = make_drive(emissions, F_ext, dt, output_steps, self.concentration_driven)
         self.out_steps = np.nonzero(drive[:, 7] >= 0)[0]          # step index of each stored row
         self.n_rows = int(self.out_steps.size)
@@ -284,6 +292,8 @@ class EnsembleEngine(CheckpointMixin):
         there: profiles/r04/auto_hist_table.txt); an explicit k_steps, or a run the small kernel does not serve, 'ksteps'."""
         if mode != "auto":
             return mode, k_steps
+        if self.compensated:                                     # the compensation words live in registers: the time-fused kernel
+            return "fused", None
         k = self.auto_k_steps() if k_steps is None else int(k_steps)
         if k <= 1:
             return "per_step", None
@@ -395,6 +405,9 @@ class EnsembleEngine(CheckpointMixin):
             raise ValueError(f"unknown mode {mode!r}")
         if self.T_hist is not None and mode not in ("fused", "per_step"):
             raise ValueError(f"mode {mode!r} does not fill T_hist: use 'fused' or 'per_step' with hist=")
+        if self.compensated and mode not in ("fused", "ksteps"):
+            raise ValueError(f"mode {mode!r} has no compensated form: the compensation words live in registers, so only the "
+                             "time-fused kernel ('fused', 'ksteps') carries them")
         if mode == "small" and not self.small_form():
             raise ValueError("mode 'small' serves runs without in-loop histograms or the inverse form, with 4 lanes per "
                              f"member for a lone 4-pool gas only (pools {self.pools}, small_lanes={self.small_lanes!r})")
@@ -409,6 +422,11 @@ class EnsembleEngine(CheckpointMixin):
                 rc = self._run_per_step(t_begin, t_end, stream, join)
             elif mode == "fused" and self.T_hist is not None:
                 rc = self._run_fused_bin_ring(t_begin, t_end, stream)
+            elif self.compensated:                                   # 'fused' / 'ksteps' without a ring: one C call
+                span = (self.fused_span_steps(t_end - t_begin) if mode == "fused" else
+                        max(self.auto_k_steps() if k_steps is None else int(k_steps), 1))
+                rc = self.lib.fiveeq_run_fused_comp_f32(*self._run_args(t_begin, t_end), span, 0.0, 1.0, 1, None, 0,
+                                                        self._stream(stream))
             elif mode == "fused":
                 span = self.fused_span_steps(t_end - t_begin)
                 if span < t_end - t_begin:                       # the same kernel, relaunched every `span` steps
@@ -577,8 +595,11 @@ class EnsembleEngine(CheckpointMixin):
         main = stream if stream is not None else torch.cuda.current_stream(dev)
         side = main if self.hist_pass_stream == "same" else concurrent_side_streams(self.lib, main, 1)[0]
         side.wait_stream(main)
-        fused = self._fn("run_fused_bins")
         lo_h, hi_h, nb = self.hist_spec
+        if self.compensated:                                     # one launch per chunk either way: k_steps = the chunk
+            fused = lambda *a: self.lib.fiveeq_run_fused_comp_f32(*a[:15], a[6] - a[5], *a[15:])     # noqa: E731
+        else:
+            fused = self._fn("run_fused_bins")
         used = [False, False]
         rc, t, i = _capi.OK, t_begin, 0
         while t < t_end and rc == _capi.OK:

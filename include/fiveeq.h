@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FIVEEQ_ABI_VERSION   10
+#define FIVEEQ_ABI_VERSION   11
 #define FIVEEQ_MAX_GAS       3
 #define FIVEEQ_MAX_POOLS     4
 #define FIVEEQ_N_BOX         2
@@ -224,6 +224,27 @@ int fiveeq_run_small_f32(const fiveeq_model *model, int64_t n_members, int64_t l
                          const float *r, const float *q, float *R, float *S,
                          float *C_traj, float *T_traj, int32_t n_rows, double *T_stats,
                          int32_t lanes_per_member, void *stream);
+/* new (ABI v11) — THE COMPENSATED fp32 FORM of the time-fused kernel (opt-in; BASELINE configs[4]'s natural mode: 100M fp32
+ * members with the state in registers).  Two changes against fiveeq_run_fused_f32 / fiveeq_run_ksteps_f32 / _fused_bins_f32,
+ * whose arguments it takes (k_steps: steps per launch, >= t_end - t_begin = one launch; bin_ring = NULL: no histogram ring and
+ * lo / hi / n_bins / ring_rows are ignored):
+ *   (1) every POOL carries a second register word holding the rounding error of its own update, fed back into the next one
+ *       (Kahan's summation with the increment's product fused into the first add): +3 instructions per pool and step, NO HBM
+ *       bytes — the words start at zero in every launch and are dropped at its end, so R / S in memory stay plain fp32 rows (a
+ *       run relaunched every k_steps steps loses at most one rounding per pool and launch).  The two thermal boxes are not
+ *       compensated: once (2) is in place their rounding is 4e-7 of T;
+ *   (2) the forcing is computed from the EXCESS C - C0 = sum_i R_i, not from the rounded C: ln(C/C0) as log1p((C - C0)/C0),
+ *       sqrt(C) - sqrt(C0) as (C - C0) / (sqrt(C) + sqrt(C0)).  In fp32 the default form loses the small excess of the first
+ *       decades to the rounding of C itself, and THAT is what bounds T in fp32, not the state.
+ * Worst relative error against 50-digit arithmetic over the 24 golden members x 750 steps: C 2.9e-6 -> 1.8e-7 (the rounding of
+ * the stored C itself), T (1e-2 K floor) 1.7e-5 -> 7e-7; cost on the VALU-bound fused kernel: profiles/r06/fp32_compensated.txt.
+ * It is its own arithmetic: results are NOT bit-identical to the default forms (which stay bit-identical among themselves), and
+ * the kernels that keep the state in HBM (step / run / run_bins / plan) do not have it. */
+int fiveeq_run_fused_comp_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                              const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                              const float *r, const float *q, float *R, float *S,
+                              float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, int32_t k_steps,
+                              double lo, double hi, int32_t n_bins, uint16_t *bin_ring, int32_t ring_rows, void *stream);
 /* lanes per member of the widest small-ensemble form compiled for (n_gas, n_pools[]): 4 (a lone 4-pool gas), 1 (every other
  * compiled layout), or 0 = the layout has no kernel at all */
 int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t *n_pools);

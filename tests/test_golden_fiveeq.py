@@ -324,3 +324,65 @@ def test_fp32_kernels_against_50_digit_arithmetic(capsys):
               f"relative error of T with a 1e-2 K floor, T error / its bound): {worst}")
     for kind, (eC, _, eT_bound) in worst.items():
         assert eC <= 5e-6 and eT_bound <= 1.0, (kind, worst[kind])
+
+
+@pytest.mark.gpu
+def test_compensated_fp32_form_against_50_digit_arithmetic(capsys):
+    """Round 6: the opt-in COMPENSATED fp32 form of the time-fused kernel (fiveeq_run_fused_comp_f32,
+    EnsembleEngine(compensated=True)) — a compensation word per pool in registers and the forcing computed from the excess
+    C - C0 — against the 50-digit reference over all 24 golden members and 750 steps: C within 5e-7, T within 3e-6
+    (relative, 1e-2 K floor); the default fp32 arithmetic is at 2.9e-6 / 1.7e-5 (the test above).  One launch, relaunched every
+    128 steps (the words are dropped at launch boundaries: at most one rounding per word and launch), K steps per launch, with the
+    streamed histograms, packed and scalar lanes (bit-identical to each other); and what the form refuses."""
+    torch = pytest.importorskip("torch")
+    from fiveeqscm_amd import _capi
+    from fiveeqscm_amd.engine import EnsembleEngine
+    ref = _load("fiveeq_mp_reference.json")
+    lib = _capi.load()
+    worst = {}
+    for kind in ("co2", "multigas"):
+        p, N = cases.members(kind)
+        runs = {}
+        for label, kw, mode, k in (("one launch", dict(fused_span=None), "fused", None), ("span 128", dict(fused_span=128), "fused", None),
+                                   ("ksteps 50", {}, "ksteps", 50), ("with hist", dict(hist=(-1.0, 8.0, 1024), hist_ring_steps=64), "fused", None),
+                                   ("scalar lanes", dict(fused_span=None), "fused", None)):
+            prev = lib.fiveeq_set_f32_packing(0) if label == "scalar lanes" else None
+            try:
+                eng = EnsembleEngine(p, N, cases.scenario(kind), dtype=torch.float32, device="cuda:0", output_steps=cases.STEPS,
+                                     compensated=True, **kw)
+                eng.run(mode=mode, k_steps=k)
+                torch.cuda.synchronize()
+            finally:
+                if prev is not None:
+                    lib.fiveeq_set_f32_packing(prev)
+            C, T = eng.C.double().cpu().numpy(), eng.T.double().cpu().numpy()
+            runs[label] = (eng.C.clone(), eng.T.clone())
+            if label == "with hist":
+                assert eng.T_hist.sum(1).tolist() == [N] * 750
+            eC = eT = 0.0
+            for i, m in enumerate(ref["members"]):
+                C_mp = np.array([[float(v) for v in row] for row in ref["cases"][kind]["C"][i]])
+                T_mp = np.array([float(v) for v in ref["cases"][kind]["T"][i]])
+                eC = max(eC, float((np.abs(C[:, :, m] - C_mp) / np.abs(C_mp)).max()))
+                eT = max(eT, float((np.abs(T[:, m] - T_mp) / (np.abs(T_mp) + 1e-2)).max()))
+            worst[(kind, label)] = (eC, eT)
+            eng.close()
+        assert torch.equal(runs["one launch"][0], runs["scalar lanes"][0]) and torch.equal(runs["one launch"][1], runs["scalar lanes"][1])
+        # (the relaunched forms drop the words at their launch boundaries: close to the one-launch run, not equal to it)
+        assert not torch.equal(runs["one launch"][0], runs["ksteps 50"][0])
+        assert (runs["one launch"][0] - runs["ksteps 50"][0]).abs().max() <= 4e-7 * runs["one launch"][0].abs().max()
+    with capsys.disabled():
+        print("\n  compensated fp32 vs 50-digit arithmetic, worst relative error (C, T with a 1e-2 K floor):")
+        for key, (eC, eT) in worst.items():
+            print(f"    {key[0]:9s} {key[1]:13s} C {eC:.2e}  T {eT:.2e}")
+    for key, (eC, eT) in worst.items():
+        assert eC <= 5e-7 and eT <= 3e-6, (key, eC, eT)
+    p, N = cases.members("co2")
+    with pytest.raises(ValueError):
+        EnsembleEngine(p, N, cases.scenario("co2"), device="cuda:0", compensated=True)                      # fp64 does not need it
+    eng = EnsembleEngine(p, N, cases.scenario("co2"), dtype=torch.float32, device="cuda:0", compensated=True)
+    assert eng.resolve_mode("auto")[0] == "fused"
+    for mode in ("per_step", "graph", "small"):
+        with pytest.raises(ValueError):
+            eng.run(mode=mode)
+    eng.close()

@@ -25,32 +25,41 @@ def main():
     N = a.members
     p = params.sample_ensemble(params.default_params("multigas"), N)
     E = emissions.rcp_like_emissions(750, 3)
-    e64 = EnsembleEngine(p, N, E, dtype=torch.float64, device="cuda:0")
-    e32 = EnsembleEngine(p, N, E, dtype=torch.float32, device="cuda:0")
-    e64.run(mode=a.mode)
-    e32.run(mode=a.mode)
+    years = [0, 99, 249, 399, 499, 749]
+    e64 = EnsembleEngine(p, N, E, dtype=torch.float64, device="cuda:0", output_steps=years)
+    e64.run(mode="fused")
     torch.cuda.synchronize()
     names = ["CO2", "CH4", "N2O"]
-    print(f"fp32 vs fp64, {N} members, 750 steps, CO2+CH4+N2O, mode={a.mode}")
-    print(f"{'year':>5s} {'qty':>4s} {'median rel':>11s} {'p99 rel':>11s} {'max rel':>11s} {'max abs':>11s}")
-    worst = 0.0
-    for t in (0, 99, 249, 399, 499, 749):
-        rows = [(names[g], e32.C[t, g].double(), e64.C[t, g]) for g in range(3)] + [("T", e32.T[t].double(), e64.T[t])]
-        for name, x32, x64 in rows:
-            err = (x32 - x64).abs()
-            rel = err / x64.abs().clamp_min(1e-30)
-            q = torch.quantile(rel[:: max(1, N // 1_000_000)], torch.tensor([0.5, 0.99], dtype=torch.float64, device=rel.device))
-            print(f"{t:5d} {name:>4s} {q[0].item():11.3e} {q[1].item():11.3e} {rel.max().item():11.3e} {err.max().item():11.3e}")
-            if t > 50:
-                worst = max(worst, rel.max().item())
-    print(f"worst relative difference after year 50: {worst:.3e}")
-    print("effect on ensemble statistics of T (fp32 - fp64):")
-    for t in (249, 499, 749):
-        s32, s64 = torch.sort(e32.T[t].double()).values, torch.sort(e64.T[t]).values
-        idx = [int(f * (N - 1)) for f in (0.05, 0.5, 0.95)]
-        d = [(s32[i] - s64[i]).item() for i in idx]
-        print(f"  year {t}: mean {(e32.T[t].double().mean() - e64.T[t].mean()).item():+.3e} K, "
-              f"p05 {d[0]:+.3e}, p50 {d[1]:+.3e}, p95 {d[2]:+.3e} K")
+    # the default fp32 arithmetic (every launch form gives these bits) and the COMPENSATED fp32 form of the time-fused kernel
+    # (round 6: a compensation word per pool and box in registers + the forcing from the excess C - C0; include/fiveeq.h)
+    for label, kw, mode in (("fp32 (default arithmetic)", {}, a.mode), ("fp32 COMPENSATED (time-fused kernel)", {"compensated": True}, "fused")):
+        e32 = EnsembleEngine(p, N, E, dtype=torch.float32, device="cuda:0", output_steps=years, **kw)
+        e32.run(mode=mode)
+        torch.cuda.synchronize()
+        print(f"{label} vs fp64, {N} members, 750 steps, CO2+CH4+N2O, mode={mode}")
+        print(f"{'year':>5s} {'qty':>4s} {'median rel':>11s} {'p99 rel':>11s} {'max rel':>11s} {'max abs':>11s}")
+        worst = 0.0
+        for k, t in enumerate(years):
+            rows = [(names[g], e32.C[k, g].double(), e64.C[k, g]) for g in range(3)] + [("T", e32.T[k].double(), e64.T[k])]
+            for name, x32, x64 in rows:
+                err = (x32 - x64).abs()
+                rel = err / x64.abs().clamp_min(1e-30)
+                q = torch.quantile(rel[:: max(1, N // 1_000_000)], torch.tensor([0.5, 0.99], dtype=torch.float64, device=rel.device))
+                print(f"{t:5d} {name:>4s} {q[0].item():11.3e} {q[1].item():11.3e} {rel.max().item():11.3e} {err.max().item():11.3e}")
+                if t > 50:
+                    worst = max(worst, rel.max().item())
+        print(f"worst relative difference after year 50: {worst:.3e}")
+        print("effect on ensemble statistics of T (fp32 - fp64):")
+        for k, t in enumerate(years):
+            if t < 200:
+                continue
+            s32, s64 = torch.sort(e32.T[k].double()).values, torch.sort(e64.T[k]).values
+            idx = [int(f * (N - 1)) for f in (0.05, 0.5, 0.95)]
+            d = [(s32[i] - s64[i]).item() for i in idx]
+            print(f"  year {t}: mean {(e32.T[k].double().mean() - e64.T[k].mean()).item():+.3e} K, "
+                  f"p05 {d[0]:+.3e}, p50 {d[1]:+.3e}, p95 {d[2]:+.3e} K")
+        e32.close()
+        print()
 
 
 if __name__ == "__main__":
