@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the beyond-Infinity-Cache roofline leg")
     ap.add_argument("--hbm-resident-members", type=int, default=8_000_000)
+    ap.add_argument("--hbm-placements", type=int, default=5,
+                    help="placements of the stored-trajectory buffers the beyond-the-cache leg measures (median reported)")
     ap.add_argument("--cpu-sample-members", type=int, default=1_500_000)
     ap.add_argument("--kernel-batches", type=int, default=5, help="event-timed batches of 100 launches for roofline")
     ap.add_argument("--timed-s", type=float, default=6.5,

@@ -364,20 +364,45 @@ def hbm_resident(eng, a, p, G, dtype, dev, n_local, best_copy_gbs, roofline):
                          store_trajectory=not a.no_trajectory, chunk_members=0)
     w = 8 if a.dtype == "f64" else 4
     resident = w * (eng.sum_pools + 2 + 3 * G + 2) * n_big
-    big.run(0, 6)
-    # five batches of 100 launches, the MEDIAN batch (single passes at this size carry a hiccup of 10-40 % now and then:
-    # profiles/r05/ab_variants.txt section 6)
-    sm = event_timed(big, lambda t0_, t1_: big.run(t0_, t1_, join=False), 0, n_s, 100, 5, lanes=big.per_step_stream_list()) / 100
-    sm_med = float(np.median(sm))
+    # `--hbm-placements` PLACEMENTS of the stored-trajectory buffers (round 6, profiles/r06/hbm_low_mode.txt): this rate moves
+    # between 0.69 and 0.80 of 8 TB/s with WHERE the driver puts C and T — the write-only rows; re-allocating them inside one
+    # process flips it, re-placing r / q / R / S does not, no L2 / EA / TLB counter or clock tells the placements apart — so one
+    # allocation is one draw.  The leg measures the engine as constructed, then re-allocates C and T (behind a random spacer, the
+    # old buffers returned to the driver) and measures again; `frac` is the MEDIAN placement, all of them are listed.
+    rng = np.random.default_rng(os.getpid())
     Ab = big.bytes_per_member_step("per_step")
+    per_placement, spacers = [], []
+    for k in range(max(1, a.hbm_placements) if big.T is not None else 1):      # (no stored rows: nothing to re-place)
+        if k > 0:
+            spacers = spacers[-2:] + [torch.empty(int(rng.integers(1, 2048)) << 20, dtype=torch.uint8, device=dev)]
+            for name in ("C", "T"):
+                old = getattr(big, name)
+                if old is not None:
+                    setattr(big, name, torch.zeros_like(old))
+                    del old
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
+            big.reset_state()
+        big.run(0, 6)
+        # batches of 100 launches, the MEDIAN batch (single passes at this size carry a hiccup of 10-40 % now and then:
+        # profiles/r05/ab_variants.txt section 6)
+        sm = event_timed(big, lambda t0_, t1_: big.run(t0_, t1_, join=False), 0, n_s, 100, 5 if k == 0 else 3,
+                         lanes=big.per_step_stream_list()) / 100
+        per_placement.append((float(np.median(sm)), float(sm.min()), float(sm.max())))
+    del spacers
+    order = sorted(range(len(per_placement)), key=lambda i: per_placement[i][0])
+    sm_med, sm_min, sm_max = per_placement[order[len(order) // 2]]         # the median placement (upper median of an even count)
     ach = Ab * n_big / sm_med / 1e9
     pools_c = (ctypes.c_int32 * G)(*big.pools)
     streamed = [bool(big.lib.fiveeq_rows_streamed(G, pools_c, n_, n_big, w)) for _, n_, _ in big.per_step_launches()]
     roofline["hbm_resident"] = {"members": n_big, "state_and_parameter_bytes": resident,
                                 "x_infinity_cache": resident / INFINITY_CACHE, "avg_launch_us": sm_med * 1e6,
-                                "batch_us_min_median_max": [float(sm.min()) * 1e6, sm_med * 1e6, float(sm.max()) * 1e6],
+                                "batch_us_min_median_max": [sm_min * 1e6, sm_med * 1e6, sm_max * 1e6],
                                 "achieved": ach, "frac": ach / HBM_PEAK_GBS, "chunk_major": False,
                                 "regime": regime(resident),
+                                "placements": {"frac_each": [Ab * n_big / v[0] / 1e9 / HBM_PEAK_GBS for v in per_placement],
+                                               "is": "the same engine with its stored-trajectory buffers (C, T) re-allocated: [0] = as "
+                                                     "constructed; `frac` = the median placement (profiles/r06/hbm_low_mode.txt)"},
                                 "rows": "streamed (non-temporal)" if all(streamed) else "cached",
                                 "frac_of_best_copy": ach / best_copy_gbs,
                                 "concurrent_launches": big.per_step_streams,

@@ -99,7 +99,6 @@ python3 $R/tools/small_ensemble_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/small_ens
 python3 $R/tools/config5_demo.py 2>&1 | grep -v amdgpu.ids > $OUT/config5_shard_end_to_end.txt
 python3 $R/tools/packed_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/packed_ab.txt
 python3 $R/tools/summary_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/summary_timing.txt
-python3 $R/tools/side_stream_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/side_stream_probe.txt
 [ -x $R/tools/microbench/hbm_rates ] && $R/tools/microbench/hbm_rates > $OUT/hbm_rates.txt 2>&1     # (built in the container: hipcc --offload-arch=gfx950 -O3)
 fi
 ls $OUT

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Run ON THE GPU BOX from the repo root (via gpurun): the evidence behind profiles/r06/hbm_low_mode.txt.
-#   bash tools/hbm_low_mode.sh [runs] [pmc_runs]
+#   bash tools/hbm_low_mode.sh [runs] [pmc_runs] [realloc_trials]
 # Phase 1: `runs` fresh processes of tools/hbm_low_mode.py (8M-member beyond-the-cache rate + the cache-resident 1M rate + driver
 #          clocks) -> low_mode_runs.jsonl;  phase 2: ONE process that re-creates the engine 12 times -> low_mode_cycles.jsonl;
 # phase 3: the same tool under rocprofv3 --pmc (the program directly after `--`, --kernel-trace only, probe off), four counter
@@ -32,4 +32,22 @@ for S in A B C D; do
   rm -rf $OUT/pmc_low_$S $OUT/pmc_low_${S}_run*.log
   echo "phase 3 set $S done"
 done
+# phase 4 (bash tools/hbm_low_mode.sh 0 0 16 runs this alone): which counters tell the slow placements of the stored-trajectory
+# buffers from the fast ones — ONE process per counter set re-allocates C and T in turn under the profiler
+# (tools/placement_probe.py realloc --only C,T); per trial the mean step_kernel duration and the counters per dispatch.
+TRIALS=${3:-0}
+if [ "$TRIALS" -gt 0 ]; then
+SETE="TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE"
+SETF="TCC_WRITE_REQ_LATENCY_sum TCC_WRITE_REQ_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE GRBM_EA_BUSY"
+SETG="TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum GRBM_GUI_ACTIVE GRBM_TC_BUSY"
+for S in E F G; do
+  eval C=\$SET$S
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_realloc_$S -- python3 $R/tools/placement_probe.py realloc --only C,T --trials $TRIALS --batches 1 \
+      > $OUT/pmc_realloc_$S.log 2>&1 || echo "pmc realloc $S failed"
+  python3 $R/tools/pmc_low_mode.py $OUT/pmc_realloc_$S $TRIALS > $OUT/realloc_pmc_$S.txt 2>&1
+  grep -h '^{' $OUT/pmc_realloc_$S.log > $OUT/realloc_pmc_${S}_lines.jsonl
+  rm -rf $OUT/pmc_realloc_$S $OUT/pmc_realloc_$S.log
+  echo "set $S done"
+done
+fi
 ls $OUT

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """EIGHT host threads enqueuing at once — in ONE process, because the GPU pool allows six processes on a card and the launcher's
-agent is one of them (tools/host_share_rehearsal.sh stops at five ranks).  Each thread owns an engine of the driver's workload
+agent is one of them (tools/rehearse_multi_gpu.sh stops at five ranks).  Each thread owns an engine of the driver's workload
 (1M fp64 members; no stored trajectory, so eight of them fit the card) and its own HIP stream pair, waits at a common barrier
 and enqueues a burst of 20 per-step timesteps on a drained device, 15 times; reported: the median enqueue time per step of the
 SLOWEST thread.  Threads of one process share the GIL (the ctypes launch calls release it) and the HIP runtime's locks, which

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2)
     ap.add_argument("--batches", type=int, default=3)
     ap.add_argument("--no-trajectory", action="store_true")
+    ap.add_argument("--only", default="r,q,R,S,C,T", help="realloc: the tensors re-allocated in turn")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -87,7 +88,8 @@ def main():
     Ab = eng.bytes_per_member_step("per_step")
     if a.mode == "realloc":
         keep = []
-        order = ["r", "q", "R", "S", "C", "T"]
+        orig_src = torch.empty(1 << 26, dtype=torch.float64, device=dev).normal_()
+        order = a.only.split(",")
         for trial in range(a.trials):
             which = None if trial == 0 else order[(trial - 1) % len(order)]
             if which is not None:
@@ -99,11 +101,35 @@ def main():
                 del old
                 if len(keep) > 6:
                     keep.pop(0)
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()                                # the freed block goes back to the driver, not to the next trial
             eng.reset_state()
             dt = measure()
+            # does a PLAIN streaming write into the same buffers see the placement too?  (non-temporal copy of 512 MiB from a fixed
+            # source into the start, the middle and the end of C and into T; GB/s written)
+            wr = {}
+            if eng.C is not None:
+                import ctypes
+                n_el = 1 << 26
+                src = orig_src
+                for name, buf in (("C", eng.C), ("T", eng.T)):
+                    flat = buf.view(-1)
+                    rates = []
+                    for start in (0, (flat.numel() // 2) // 1024 * 1024, (flat.numel() - n_el) // 1024 * 1024):
+                        dst_ptr = flat.data_ptr() + start * 8
+                        call = lambda: eng.lib.fiveeq_stream_copy_nt_f64(n_el, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst_ptr), eng._stream())  # noqa: E731
+                        call()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(4):
+                            call()
+                        e1.record()
+                        e1.synchronize()
+                        rates.append(round(4 * n_el * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1))
+                    wr[name] = rates
             print(json.dumps({"mode": a.mode, "trial": trial, "which": which, "us_per_step": dt * 1e6,
-                              "frac_of_8TBs": Ab * N / dt / 8e12,
-                              "ptrs": {k: hex(getattr(eng, k).data_ptr()) for k in order}}), flush=True)
+                              "frac_of_8TBs": Ab * N / dt / 8e12, "nt_copy_into_GBs_written": wr,
+                              "ptrs": {k: hex(getattr(eng, k).data_ptr()) for k in ("r", "q", "R", "S", "C", "T")}}), flush=True)
         return
     for trial in range(a.trials):
         off = packed()
