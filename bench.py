@@ -276,10 +276,10 @@ def main():
 
         # how long IS a block inside a run?  The wall-clocked first block carries the idle-stream launch latency (10 % at 20
         # steps); a short event-timed burst sizes the main loop so that it clocks --timed-s of device time, not 10 % less
-        est = first_max
-        if 12 * first_max < a.timed_s:
-            probe, _, t_idx = clock_blocks(11, t_idx)
-            est = float(np.median(ctl.max_over_ranks(probe)))
+        # (always: on a box's first process the wall-clocked block has been seen 60x too long — 43 ms for 60 steps of 36 us — and a
+        # main loop sized from it clocked 2 ms where 50 were asked for)
+        probe, _, t_idx = clock_blocks(int(min(11, max(1, a.timed_s // max(first_max, 1e-6)))), t_idx)
+        est = float(np.median(ctl.max_over_ranks(probe)))
         repeats = int(min(max(a.max_repeats, 1), -(-a.timed_s // max(est, 1e-6)))) | 1     # odd
         blocks, wall_all, t_idx = clock_blocks(repeats, t_idx)
     per_rank_ms_per_step = ctl.gather_over_ranks(float(np.median(blocks)) / a.steps * 1e3)      # each rank's own median block

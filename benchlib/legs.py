@@ -264,7 +264,8 @@ def fused_roofline(eng, a, mode_run, k_steps, n_local):
     reps = -(-N_SCEN // span)
     k_avg = float(samples.mean())                           # seconds per model step inside the kernel
     achieved = A * n_local / k_avg / 1e9
-    kernel_name = ((f"fiveeq::small_kernel<{lname},false>" if single else f"fiveeq::small_multi_kernel<{lname},false>")
+    kernel_name = ((f"fiveeq::small_kernel<{lname},false>" if single else
+                    (f"fiveeq::small_octet_kernel<{tname}>" if lpm == 8 else f"fiveeq::small_multi_kernel<{lname},false>"))
                    if kname == "small_kernel" else f"fiveeq::{kname}<{lname},{pools3}>")
     roofline = {"bound": "fp64-valu" if a.dtype == "f64" else "fp32-valu", "unit": "wave-instr/s",
                 "achieved": None, "peak": valu_peak, "frac": None, "traffic": None,

@@ -400,9 +400,9 @@ int run_fused_comp(const fiveeq_model* m, int64_t n, int64_t ld, const float* dr
 }
 
 // ---- small ensembles: one member per quad of lanes (small_kernel), several gases one per lane (small_multi_kernel) -----
-// lanes per member of the widest small-ensemble form compiled for a layout: 4 for a lone 4-pool gas, 1 for every other
-// compiled layout, 0 = none
-int small_lanes(int code) { return code == 400 ? 4 : (layout_ok(code) ? 1 : 0); }
+// lanes per member of the widest small-ensemble form compiled for a layout: 4 for a lone 4-pool gas (a quad), 8 for 4 + 1 + 1
+// (an octet: small_octet_kernel), 1 for every other compiled layout, 0 = none
+int small_lanes(int code) { return code == 400 ? 4 : (code == 411 ? 8 : (layout_ok(code) ? 1 : 0)); }
 
 template <typename T>
 int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int32_t n_steps, int32_t t_begin,
@@ -411,9 +411,12 @@ int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     RunArgs<T> a;
     if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
     const int widest = small_lanes(a.code);
-    if (lanes == 0) lanes = widest;
+    if (lanes == 0) lanes = (widest == 8 && a.stats != nullptr) ? 1 : widest;      // the octet form writes no statistics records
     if (lanes != 1 && lanes != widest)
-        return fail(FIVEEQ_E_INVALID, "lanes_per_member=%d: pool layout %03d takes 1%s", lanes, a.code, widest == 4 ? " or 4" : "");
+        return fail(FIVEEQ_E_INVALID, "lanes_per_member=%d: pool layout %03d takes 1%s", lanes, a.code,
+                    widest == 4 ? " or 4" : (widest == 8 ? " or 8" : ""));
+    if (lanes == 8 && a.stats != nullptr)
+        return fail(FIVEEQ_E_INVALID, "lanes_per_member=8 writes no per-wave statistics (T_stats must be NULL): use 1");
     if (t_begin == t_end) return FIVEEQ_OK;
     const int64_t per_block = FIVEEQ_SMALL_BLOCK / lanes;
     const int64_t blocks = (a.n + per_block - 1) / per_block;
@@ -432,6 +435,10 @@ int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
         case 3001: FIVEEQ_SMALL1(3, 1)
         case 4001: FIVEEQ_SMALL1(4, 1)
         case 4004: FIVEEQ_SMALL1(4, 4)
+        case 4118:
+            hipLaunchKernelGGL((small_octet_kernel<T>), grid, block, 0, st, a.km, a.drive, a.n_steps, t_begin, t_end, a.n, a.ld, a.r, a.q,
+                               a.R, a.S, a.C_traj, a.T_traj, a.n_rows);
+            break;
 #define X(p0, p1, p2)                                                                                              \
     case ((p0) * 100 + (p1) * 10 + (p2)) * 10 + 1:                                                                 \
         if constexpr ((p1) > 0) {                                                                                  \

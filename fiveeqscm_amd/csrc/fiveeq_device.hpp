@@ -1356,6 +1356,158 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
 }
 
 // ---------------------------------------------------------------------------------
+// Kernel 2d — SMALL MULTI-GAS ENSEMBLES: one member per OCTET of lanes (round 6; layout 4 + 1 + 1, the default three-gas set).
+//
+// The quad idea of small_kernel carried to three gases: lanes 0-3 of an octet hold the four pools of gas 0, lane 4 the pool of
+// gas 1, lane 5 the pool of gas 2 (lanes 6, 7 shadow lane 5 and store nothing).  Every lane runs ONE alpha closure, ONE expm1
+// chain, ONE pool update and ONE forcing — its own gas's, with that gas's constants selected into registers once — where the
+// one-member-per-lane form (small_multi_kernel) runs three closures, six expm1 chains and three forcings per wave-step: a third
+// of the instructions per wave, on 8x the waves.  What crosses lanes, all of it DPP moves inside a row of 16 lanes:
+//   * gas 0's sum over pools, folded inside its quad in member_step()'s order (((0 + R0) + R1) + R2) + R3; a single-pool gas's
+//     sum is 0 + R, lane-local; one select between the two;
+//   * the three forcings: quad_perm broadcasts lane 0 / lane 1 of every quad (quad 0: F_0, F_0; quad 1: F_1, F_2), row_shr:4 /
+//     row_shl:4 under a bank mask carry them into the other quad, and every lane adds F_ext + F_0 + F_1 + F_2 in that order.
+// The thermal boxes are computed by all eight lanes alike.  Same operations on the same values in the same order as
+// member_step(): bit-identical results (tested against the per-step path, fp64 and fp32).  No per-wave statistics (a record
+// is 64 members = eight of these waves; runs with collect_stats take the one-lane form).
+// ---------------------------------------------------------------------------------
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double dpp_merge(const double old, const double src) {       // lanes of the banks in BANKS: src moved by CTRL; others: old
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_merge(const float old, const float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, BANKS, false));
+}
+constexpr int DPP_ROW_SHL4 = 0x104, DPP_ROW_SHR4 = 0x114;          // lane i reads lane i + 4 / lane i - 4 of its row of 16
+
+template <typename T>
+__global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void small_octet_kernel(
+    const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
+    const int64_t n, const int64_t ld, const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R,
+    T* __restrict__ S, T* __restrict__ C_traj /* [n_rows][3][ld] or nullptr */, T* __restrict__ T_traj /* [n_rows][ld] or nullptr */,
+    const int n_rows) {
+    constexpr int MPB = FIVEEQ_SMALL_BLOCK / 8;                          // members per workgroup
+    __shared__ T drv[FIVEEQ_FUSED_CHUNK * DRIVE_STRIDE];
+    __shared__ int row_s[FIVEEQ_FUSED_CHUNK];
+    const int lane = threadIdx.x;
+    const int o = lane & 7;                                              // position in the octet
+    const int g = o < 4 ? 0 : (o == 4 ? 1 : 2);                          // this lane's gas
+    const int prow = o < 4 ? o : (o == 4 ? 4 : 5);                       // ... and its pool's row of R
+    const bool co2 = o < 4;
+    const int64_t m = (int64_t)blockIdx.x * MPB + lane / 8;
+    const bool active = m < n;
+    const int64_t mm = active ? m : 0;                                   // idle tail lanes shadow member 0 and store nothing
+    // this lane's gas, selected once from the kernel argument (scalar loads) into vector registers
+#define FIVEEQ_PICK(field) (g == 0 ? km.gas[0].field : (g == 1 ? km.gas[1].field : km.gas[2].field))
+    const T ndt = co2 ? (o == 0 ? km.gas[0].ndt_over_tau[0] : (o == 1 ? km.gas[0].ndt_over_tau[1] : (o == 2 ? km.gas[0].ndt_over_tau[2] : km.gas[0].ndt_over_tau[3])))
+                      : (g == 1 ? km.gas[1].ndt_over_tau[0] : km.gas[2].ndt_over_tau[0]);
+    const T natc = -(co2 ? (o == 0 ? km.gas[0].atc[0] : (o == 1 ? km.gas[0].atc[1] : (o == 2 ? km.gas[0].atc[2] : km.gas[0].atc[3])))
+                         : (g == 1 ? km.gas[1].atc[0] : km.gas[2].atc[0]));
+    const T g0 = FIVEEQ_PICK(g0), inv_g1 = FIVEEQ_PICK(inv_g1), ra = FIVEEQ_PICK(ra), inv_c = FIVEEQ_PICK(inv_c);
+    const T C0 = FIVEEQ_PICK(C0), inv_C0 = FIVEEQ_PICK(inv_C0), sqrtC0 = FIVEEQ_PICK(sqrtC0);
+    const T f1 = FIVEEQ_PICK(f1), f2 = FIVEEQ_PICK(f2), f3 = FIVEEQ_PICK(f3);
+#undef FIVEEQ_PICK
+    const bool has_log = f1 != T(0), has_sqrt = f3 != T(0);
+    T rr[3], qq[2], Sv[2];
+    T Rv = R[prow * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) Sv[k] = S[k * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rr[k] = r[(3 * g + k) * ld + mm];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) qq[k] = q[k * ld + mm];
+    // ONE store per step and lane: lanes 0 / 4 / 5 write their gas's C, lane 1 writes T (null = this lane stores nothing)
+    T* out_p = nullptr;
+    int64_t out_stride = 0;
+    if (active) {
+        if (o == 1) out_p = T_traj ? T_traj + m : nullptr, out_stride = ld;
+        else if (o == 0 || o == 4 || o == 5) out_p = C_traj ? C_traj + g * ld + m : nullptr, out_stride = 3 * ld;
+    }
+    // the sum over this lane's gas's pools of the CURRENT state, as small_kernel keeps it (a step's own sum is the next step's)
+    T sumR;
+    {
+        T s4 = quad_bcast<0>(Rv);
+        s4 += quad_bcast<1>(Rv);
+        s4 += quad_bcast<2>(Rv);
+        s4 += quad_bcast<3>(Rv);
+        sumR = co2 ? s4 : Rv;
+    }
+    for (int tc = t_begin; tc < t_end; tc += FIVEEQ_FUSED_CHUNK) {
+        const int nt = min(FIVEEQ_FUSED_CHUNK, t_end - tc);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt * DRIVE_STRIDE; i += FIVEEQ_SMALL_BLOCK) {
+            const T v = drive[(int64_t)tc * DRIVE_STRIDE + i];
+            drv[i] = v;
+            if ((i & (DRIVE_STRIDE - 1)) == 7) row_s[i >> 3] = (int)v;
+        }
+        __syncthreads();
+        T E = drv[g], cumE = drv[3 + g], Fx = drv[6];                    // step tc: this lane's gas's emission and cumulative emission
+        int rowv = row_s[0];
+        for (int k = 0; k < nt; ++k) {
+            const int kn = k + 1 < nt ? k + 1 : k;                       // the NEXT step's record, asked for now
+            const T En = drv[kn * DRIVE_STRIDE + g], cumEn = drv[kn * DRIVE_STRIDE + 3 + g], Fxn = drv[kn * DRIVE_STRIDE + 6];
+            const int rowvn = row_s[kn];
+            // ---- gas_step<.., g, INV = false>, operation for operation, for THIS lane's gas and pool ----
+            const T T_old = Sv[0] + Sv[1];
+            const T G_a = sumR * inv_c;
+            const T G_u = cumE - G_a;
+            T iirf = fe_fma(ra, G_a, fe_fma(rr[2], T_old, fe_fma(rr[1], G_u, rr[0])));
+            iirf = fe_min(iirf, km.iirf_max);
+            const T alpha = g0 * fe_exp(iirf * inv_g1);
+            const T inv_alpha = fe_rcp(alpha);
+            const T Ea = E * alpha;
+            const T em1 = fe_expm1_neg(ndt * inv_alpha);
+            const T Rn = fe_fma(em1, fe_fma(natc, Ea, Rv), Rv);
+            Rv = Rn;
+            T s4 = T(0);
+            s4 += quad_bcast<0>(Rn);
+            s4 += quad_bcast<1>(Rn);
+            s4 += quad_bcast<2>(Rn);
+            s4 += quad_bcast<3>(Rn);
+            const T s1 = T(0) + Rn;
+            const T sumN = co2 ? s4 : s1;
+            sumR = sumN;
+            const T Cg = C0 + sumN;
+            const bool pos = Cg > T(0);
+            T Fg = f2 * (Cg - C0);
+            {
+                const T lg = fe_log(pos ? Cg * inv_C0 : T(1));
+                const T with_log = fe_fma(f1, lg, Fg);
+                Fg = (has_log && pos) ? with_log : Fg;
+                const T sq = fe_sqrt(pos ? Cg : T(1));
+                const T with_sqrt = fe_fma(f3, (pos ? sq : T(0)) - sqrtC0, Fg);
+                Fg = has_sqrt ? with_sqrt : Fg;
+            }
+            // ---- the three gases' forcings to every lane of the octet ----
+            const T a0 = quad_bcast<0>(Fg);                              // quad 0: F_0 (lane 0's); quad 1: F_1 (lane 4's)
+            const T a1 = quad_bcast<1>(Fg);                              // quad 0: F_0 (lane 1's); quad 1: F_2 (lane 5's)
+            const T F0 = dpp_merge<DPP_ROW_SHR4, 0xA>(a0, a0);           // quads 1, 3 of the row take their left neighbour's
+            const T F1 = dpp_merge<DPP_ROW_SHL4, 0x5>(a0, a0);           // quads 0, 2 take their right neighbour's
+            const T F2 = dpp_merge<DPP_ROW_SHL4, 0x5>(a1, a1);
+            T F = Fx;
+            F += F0;
+            F += F1;
+            F += F2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Sv[j] = fe_fma(km.em1_d[j], fe_fma(-qq[j], F, Sv[j]), Sv[j]);
+            const T Tn = Sv[0] + Sv[1];
+            const int row = __builtin_amdgcn_readfirstlane(rowv);
+            if (row >= 0 && row < n_rows) {
+                if (out_p != nullptr) out_p[(int64_t)row * out_stride] = o == 1 ? Tn : Cg;
+            }
+            E = En, cumE = cumEn, Fx = Fxn, rowv = rowvn;
+        }
+    }
+    if (active) {
+        if (o < 6) R[prow * ld + m] = Rv;
+        if (o < 2) S[o * ld + m] = o == 0 ? Sv[0] : Sv[1];
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // LDS counter increment with ONE round of wave-level aggregation (the histogram passes and the pick pass).  In the first decades of a run every member's T sits in a
 // handful of bins: 64 lanes adding to the same LDS dword serialise (the first two 64-step chunks of a streamed run took
 // 1.9 and 0.8 ms in the histogram pass against 0.35 ms later).

@@ -59,6 +59,9 @@ FUSED_SPAN_MIN_ROUNDS = 0.25         # ... and from this many on
 # members, 0.89 / 1.09 one lane / fused at 110k, 1.74 / 1.90 at 250k; three gases: 0.94 / 1.38 at 10k, 1.66 / 1.98 at 110k,
 # 2.40 / 2.65 at 150k: profiles/r05/small_ensemble_ab.txt, small_ensemble_multigas_ab.txt, auto_window_sweep.txt)
 SMALL_QUAD_MEMBERS_PER_CU = 64
+# ... and the 4 + 1 + 1 layout one member per OCTET of lanes (round 6, small_octet_kernel: 8 members per wave) up to this many
+# members per CU; past it the one-lane form (profiles/r06/small_octet_ab.txt)
+SMALL_OCTET_MEMBERS_PER_CU = 64
 KSTEPS_LAUNCH_BOUND = 128            # steps per launch of the K-step form on a launch-bound ensemble (2 / 8 / 32 / 128 steps per
                                      # launch at 110k three-gas members: 4.42 / 2.70 / 2.13 / 1.97 us per step; one launch: 1.98)
 
@@ -129,7 +132,8 @@ class EnsembleEngine(CheckpointMixin):
         arithmetic C 2.9e-6 -> 1.8e-7, T 1.7e-5 -> 7e-7.  Its own arithmetic: not bit-identical to the default forms; the modes
         that keep the state in HBM between launches ('per_step', 'graph') and the small-ensemble kernels refuse it.
         small_lanes: mode='small' (no in-loop histograms): lanes per member, 4 (a lone 4-pool gas: one pool per lane of a
-        quad), 1 (any layout), or "auto" = 4 where the layout has it and every quad wave gets a SIMD of its own, else 1."""
+        quad), 8 (the 4 + 1 + 1 layout: one pool per lane of an octet; no collect_stats), 1 (any layout), or "auto" = the widest
+        form the layout has while the ensemble is small enough for it (SMALL_*_MEMBERS_PER_CU), else 1."""
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.lib = _capi.load(lib_path)    # raises if the HIP library is not built
@@ -227,8 +231,8 @@ class EnsembleEngine(CheckpointMixin):
         if fused_span not in ("auto", None) and int(fused_span) < 1:
             raise ValueError("fused_span must be 'auto', None or a positive number of steps")
         self.fused_span = fused_span if fused_span in ("auto", None) else int(fused_span)
-        if small_lanes != "auto" and int(small_lanes) not in (1, 4):
-            raise ValueError("small_lanes must be 'auto', 1 or 4")
+        if small_lanes != "auto" and int(small_lanes) not in (1, 4, 8):
+            raise ValueError("small_lanes must be 'auto', 1, 4 or 8")
         self.small_lanes = small_lanes if small_lanes == "auto" else int(small_lanes)
         # run(..., join=False) left work nobody has waited for: the streams of THAT run ([its main, its side streams]) — join()
         # waits for exactly these, whichever stream the consumer is on; None = nothing outstanding
@@ -280,10 +284,17 @@ class EnsembleEngine(CheckpointMixin):
         wants in-loop histograms or the concentration-driven form."""
         if not self.small_widest or self.T_hist is not None or self.concentration_driven:
             return 0
+        octet_ok = self.small_widest == 8 and not self.collect_stats       # the octet form writes no per-wave statistics
         if self.small_lanes != "auto":
+            if self.small_lanes == 8:
+                return 8 if octet_ok else 0
             return self.small_lanes if self.small_lanes in (1, self.small_widest) else 0
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-        return 4 if self.small_widest == 4 and self.n_members <= SMALL_QUAD_MEMBERS_PER_CU * cus else 1
+        if self.small_widest == 4 and self.n_members <= SMALL_QUAD_MEMBERS_PER_CU * cus:
+            return 4
+        if octet_ok and self.n_members <= SMALL_OCTET_MEMBERS_PER_CU * cus:
+            return 8
+        return 1
 
     def resolve_mode(self, mode, k_steps=None):
         """(mode, k_steps) run() uses for a request: 'auto' resolved, everything else as given.  'auto' is 'per_step' (the
@@ -410,7 +421,8 @@ class EnsembleEngine(CheckpointMixin):
                              "time-fused kernel ('fused', 'ksteps') carries them")
         if mode == "small" and not self.small_form():
             raise ValueError("mode 'small' serves runs without in-loop histograms or the inverse form, with 4 lanes per "
-                             f"member for a lone 4-pool gas only (pools {self.pools}, small_lanes={self.small_lanes!r})")
+                             "member for a lone 4-pool gas only and 8 for pools [4, 1, 1] without collect_stats "
+                             f"(pools {self.pools}, small_lanes={self.small_lanes!r})")
         with torch.cuda.device(self.device):
             self._wave_stats()
             self._step_sums_valid[t_begin:t_end] = False     # these launches write per-wave records: older folded sums are stale

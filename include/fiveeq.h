@@ -207,8 +207,11 @@ int fiveeq_run_ksteps_f32(const fiveeq_model *model, int64_t n_members, int64_t 
  * instructions one wave issues per step; with lanes_per_member = 4 (pool layouts {4}: a lone 4-pool gas) lane 4m + i carries
  * pool i of member m — one expm1 chain per wave-step instead of four, the two sums over pools folded with DPP moves in the
  * per-step kernel's order ((R0 + R1) + R2) + R3 — and the shared model stays in registers instead of LDS.  4x the waves of
- * fiveeq_run_fused_*, 16 members per wave.  lanes_per_member: 4, 1 (one member per lane with the model in registers: every
- * compiled layout, several gases included) or 0 = the widest form the layout has (fiveeq_small_lanes).  One launch for the
+ * fiveeq_run_fused_*, 16 members per wave.  lanes_per_member: 4, 8 (new, ABI v11: the 4 + 1 + 1 layout on an OCTET of lanes —
+ * gas 0's four pools on lanes 0-3, the single pools of gases 1 and 2 on lanes 4 and 5: every lane runs one gas's closure, one
+ * expm1 chain and one forcing, a third of the one-lane form's instructions per wave; T_stats must be NULL for it), 1 (one member
+ * per lane with the model in registers: every compiled layout, several gases included) or 0 = the widest form the layout has
+ * (fiveeq_small_lanes; the one-lane form when a 4 + 1 + 1 run asks for statistics).  One launch for the
  * whole span; C_traj, T_traj, the row map and T_stats as in the other entry points (the statistics records are the fused
  * kernel's bit for bit).  Same arithmetic operation for operation: bit-identical results to the per-step path.
  * Ahead of the fused kernel while the ensemble is launch-bound — about 64 members per CU for the quad form, a few hundred
@@ -245,8 +248,8 @@ int fiveeq_run_fused_comp_f32(const fiveeq_model *model, int64_t n_members, int6
                               const float *r, const float *q, float *R, float *S,
                               float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, int32_t k_steps,
                               double lo, double hi, int32_t n_bins, uint16_t *bin_ring, int32_t ring_rows, void *stream);
-/* lanes per member of the widest small-ensemble form compiled for (n_gas, n_pools[]): 4 (a lone 4-pool gas), 1 (every other
- * compiled layout), or 0 = the layout has no kernel at all */
+/* lanes per member of the widest small-ensemble form compiled for (n_gas, n_pools[]): 4 (a lone 4-pool gas), 8 (4 + 1 + 1),
+ * 1 (every other compiled layout), or 0 = the layout has no kernel at all */
 int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t *n_pools);
 
 /* The fp32 entry points (step / run / run_fused / run_ksteps / run_*bins / plan_create _f32) compute TWO members per

@@ -194,13 +194,16 @@ def test_new_entry_points_validate_on_the_host():
     common = (ctypes.byref(m), 8, 8, p, 4, 0, 4, p, p, p, p, None, None, 0, None)
     assert lib.fiveeq_run_ksteps_f64(*common, 0, None) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
     assert lib.fiveeq_run_ksteps_f32(*common, -3, None) == _capi.E_INVALID
-    # the small-ensemble kernel: 4 lanes per member for a lone 4-pool gas, 1 for every other compiled layout
+    # the small-ensemble kernels: 4 lanes per member for a lone 4-pool gas, 8 for 4 + 1 + 1, 1 for every other compiled layout
     lanes = lambda *pl: lib.fiveeq_small_lanes(len(pl), (ctypes.c_int32 * len(pl))(*pl))   # noqa: E731
-    assert [lanes(4), lanes(1), lanes(2), lanes(3), lanes(4, 1, 1), lanes(1, 1), lanes(4, 4, 4), lanes(5), lanes(2, 3)] == [4, 1, 1, 1, 1, 1, 1, 0, 0]
+    assert [lanes(4), lanes(1), lanes(2), lanes(3), lanes(4, 1, 1), lanes(1, 1), lanes(4, 4, 4), lanes(5), lanes(2, 3)] == [4, 1, 1, 1, 8, 1, 1, 0, 0]
     small = lambda model, n_lanes, t0=0, t1=4: lib.fiveeq_run_small_f64(ctypes.byref(model), 8, 8, p, 4, t0, t1, p, p, p, p, None,   # noqa: E731
                                                                        None, 0, None, n_lanes, None)
-    assert small(m, 4) == _capi.E_INVALID and b"lanes_per_member" in lib.fiveeq_last_error()    # three gases: one lane only
-    assert small(m, 0, 2, 2) == _capi.OK and small(m, 1, 2, 2) == _capi.OK
+    assert small(m, 4) == _capi.E_INVALID and b"1 or 8" in lib.fiveeq_last_error()              # 4 + 1 + 1: one lane or an octet
+    assert small(m, 0, 2, 2) == _capi.OK and small(m, 1, 2, 2) == _capi.OK and small(m, 8, 2, 2) == _capi.OK
+    with_stats = lambda n_lanes: lib.fiveeq_run_small_f64(ctypes.byref(m), 8, 8, p, 4, 2, 2, p, p, p, p, None, None, 0, p, n_lanes, None)   # noqa: E731
+    assert with_stats(8) == _capi.E_INVALID and b"statistics" in lib.fiveeq_last_error()       # the octet form writes no records
+    assert with_stats(0) == _capi.OK and with_stats(1) == _capi.OK                              # "widest" then means one lane
     co2 = prm.make_model(prm.default_params("co2"))
     assert small(co2, 2) == _capi.E_INVALID and b"lanes_per_member" in lib.fiveeq_last_error()
     assert small(co2, -1) == _capi.E_INVALID

@@ -377,6 +377,81 @@ def test_small_ensemble_kernel_ragged_sizes_layouts_and_resume(gpu):
     ref.close()
 
 
+def test_small_multi_gas_ensembles_one_member_per_octet_of_lanes(gpu):
+    """Round 6 (DESIGN r05 section 8 item 2): the 4 + 1 + 1 layout on an OCTET of lanes — gas 0's four pools on lanes 0-3, the
+    single pools of gases 1 and 2 on lanes 4 and 5, every lane running ONE gas's closure / expm1 chain / forcing, the sums and the
+    three forcings carried across lanes by DPP moves in member_step()'s order.  10,000 three-gas members x 750 steps against the
+    C oracle at 1e-10 and torch.equal to the per-step path; ragged sizes (the last octet / wave / workgroup partly idle), both
+    precisions, selected rows, no stored concentrations, a resumed run, a member sub-range of a larger allocation, random
+    forcing coefficients (log / linear / square-root terms on or exactly off per gas); and what the form refuses."""
+    from fiveeqscm_amd import _capi
+    lib = _capi.load()
+    N, n_steps = 10_000, 750
+    p = prm.sample_ensemble(prm.default_params("multigas"), N)
+    E = emi.rcp_like_emissions(n_steps, 3)
+    want = c_oracle.run(E, p, N, n_threads=8)
+    ref = _engine(p, N, E)
+    ref.run(mode="per_step")
+    for lanes in (8, "auto"):
+        eng = _engine(p, N, E, small_lanes=lanes)
+        assert eng.small_widest == 8 and eng.small_form() == 8
+        eng.run(mode="small" if lanes == 8 else "auto")
+        torch.cuda.synchronize()
+        assert eng.last_mode == "small"
+        _close(eng.C, want["C"], what="C octet")
+        _close(eng.T, want["T"], what="T octet")
+        for name in ("C", "T", "R", "S"):
+            assert torch.equal(getattr(eng, name), getattr(ref, name)), (lanes, name)
+        eng.close()
+    ref.close()
+    rng = np.random.default_rng(77)
+    n_steps = 140                                                    # > one 125-step chunk of the drive table
+    E = emi.rcp_like_emissions(750, 3)[200:200 + n_steps]
+    for N in (1, 7, 8, 9, 31, 32, 33, 255, 256, 257, 1000, 8193):
+        for td in (torch.float64, torch.float32):
+            base = dict(prm.default_params("multigas"))
+            f = np.array(base["f"], dtype=np.float64)
+            f[rng.uniform(size=f.shape) < 0.3] = 0.0                 # a term switched off exactly: selected away, not branched around
+            f[rng.uniform(size=f.shape) < 0.2] = 0.01
+            base["f"] = f
+            p = prm.sample_ensemble(base, N, seed=N)
+            kw = dict(dtype=td, output_steps=sorted(set(int(v) for v in rng.integers(0, n_steps, size=5))),
+                      store_concentrations=bool(rng.integers(0, 2)))
+            ref = _engine(p, N, E, **kw)
+            ref.run(mode="per_step")
+            eng = _engine(p, N, E, small_lanes=8, **kw)
+            cut = int(rng.integers(1, n_steps))
+            eng.run(0, cut, mode="small")
+            eng.run(cut, n_steps, mode="small")
+            torch.cuda.synchronize()
+            for name in ("T", "R", "S") + (("C",) if kw["store_concentrations"] else ()):
+                assert torch.equal(getattr(eng, name), getattr(ref, name)), (N, td, cut, name)
+            eng.close(), ref.close()
+    N = 1000
+    p = prm.sample_ensemble(prm.default_params("multigas"), N, seed=9)
+    ref = _engine(p, N, E)
+    ref.run(mode="per_step")
+    for m0, n in ((0, 999), (128, 129), (1, 998), (333, 64), (999, 1)):
+        eng = _engine(p, N, E)
+        rc = lib.fiveeq_run_small_f64(*eng._run_args(0, n_steps, m0, n), 8, eng._stream())
+        assert rc == 0, lib.fiveeq_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(eng.T[:, m0:m0 + n], ref.T[:, m0:m0 + n]) and torch.equal(eng.R[:, m0:m0 + n], ref.R[:, m0:m0 + n])
+        assert torch.equal(eng.C[:, :, m0:m0 + n], ref.C[:, :, m0:m0 + n]) and torch.equal(eng.S[:, m0:m0 + n], ref.S[:, m0:m0 + n])
+        assert int((eng.T[:, :m0] != 0).sum()) == 0 and int((eng.T[:, m0 + n:] != 0).sum()) == 0, (m0, n)
+        assert int((eng.R[:, :m0] != 0).sum()) == 0 and int((eng.R[:, m0 + n:] != 0).sum()) == 0, (m0, n)
+        eng.close()
+    ref.close()
+    # statistics records: the octet form writes none — refused when asked for by name, the one-lane form when left to choose
+    st = _engine(p, N, E, collect_stats=True)
+    assert st.small_form() == 1
+    with pytest.raises(ValueError, match="small"):
+        _engine(p, N, E, collect_stats=True, small_lanes=8).run(mode="small")
+    with pytest.raises(ValueError, match="small"):
+        _engine(prm.sample_ensemble(prm.default_params("co2"), 50), 50, emi.rcp_like_emissions(20, 1), small_lanes=8).run(mode="small")
+    st.close()
+
+
 def test_auto_takes_the_small_ensemble_kernel_where_the_measured_table_says(gpu):
     """profiles/r05/small_ensemble_ab.txt, auto_window_sweep.txt: a launch-bound ensemble takes the small-ensemble kernel — the
     quad form while its waves get a SIMD each (64 members per CU), else one member per lane — and an ensemble whose step hides
@@ -397,7 +472,11 @@ def test_auto_takes_the_small_ensemble_kernel_where_the_measured_table_says(gpu)
     assert _engine(p, 5000, emi.rcp_like_emissions(750, 1)).auto_k_steps() == 128
     pm = prm.sample_ensemble(prm.default_params("multigas"), 5000)
     em = _engine(pm, 5000, emi.rcp_like_emissions(30, 3))
-    assert em.small_widest == 1 and em.resolve_mode("auto")[0] == "small" and em.small_form() == 1     # three gases: one lane
+    assert em.small_widest == 8 and em.resolve_mode("auto")[0] == "small" and em.small_form() == 8     # 4 + 1 + 1: an octet per member
+    assert _engine(pm, 5000, emi.rcp_like_emissions(30, 3), collect_stats=True).small_form() == 1       # ... one lane with statistics
+    big_m = 64 * cus + 1
+    assert _engine(prm.sample_ensemble_shard(prm.default_params("multigas"), big_m, device="cuda:0"), big_m,
+                   emi.rcp_like_emissions(30, 3)).small_form() == 1                                     # ... and past 64 members per CU
     with pytest.raises(ValueError, match="small"):
         _engine(pm, 5000, emi.rcp_like_emissions(30, 3), small_lanes=4).run(mode="small")
     with pytest.raises(ValueError, match="small"):

@@ -218,7 +218,7 @@ def test_the_ode_reference_script_reproduces_its_fixture():
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["co2", "multigas"])
-@pytest.mark.parametrize("mode", ["per_step", "fused", "ksteps", "small"])
+@pytest.mark.parametrize("mode", ["per_step", "fused", "ksteps", "small", "small1"])
 def test_kernels_reproduce_the_golden_trajectories(golden, kind, mode):
     """The HIP kernels, through the C ABI, against the committed oracle trajectories: <= 1e-10 relative on C and T
     (BASELINE.json north_star), and against the 50-digit reference at the same tolerance."""
@@ -228,9 +228,13 @@ def test_kernels_reproduce_the_golden_trajectories(golden, kind, mode):
     rec = golden["cases"][kind]
     G = 1 if kind == "co2" else 3
     eng = EnsembleEngine(p, N, cases.scenario(kind), device="cuda:0", output_steps=cases.STEPS)
-    # 'small': a lone 4-pool gas runs one member per quad of lanes (small_kernel), three gases one member per lane on the
-    # register-resident model (small_multi_kernel) — the form mode='auto' picks for every launch-bound multi-gas ensemble
-    assert mode != "small" or eng.small_form() == (4 if kind == "co2" else 1)
+    # 'small': a lone 4-pool gas runs one member per quad of lanes (small_kernel), the 4 + 1 + 1 set one member per OCTET
+    # (small_octet_kernel, round 6) — the forms mode='auto' picks for these launch-bound ensembles; 'small1': one member per lane
+    # on the register-resident model (small_multi_kernel), what every other multi-gas layout and runs with statistics take
+    if mode == "small1":
+        eng.small_lanes, mode = 1, "small"
+    else:
+        assert mode != "small" or eng.small_form() == (4 if kind == "co2" else 8)
     eng.run(mode=mode)
     torch.cuda.synchronize()
     S = len(cases.STEPS)

@@ -29,7 +29,7 @@ for N in sizes:
     ref = [eng.C.clone(), eng.T.clone(), eng.R.clone(), eng.S.clone()]
     out, same = {}, True
     forms = [("fused", "fused", {}), ("fused1", "fused", {"span": None}), ("ksteps", "ksteps", {}), ("small1", "small", {"lanes": 1})]
-    forms += [("small4", "small", {"lanes": 4})] if eng.small_widest == 4 else []
+    forms += [("small4", "small", {"lanes": eng.small_widest})] if eng.small_widest in (4, 8) and not stats else []      # (column "small4": the quad / octet form)
     out["small4"] = float("nan")
     for name, mode, kw in forms:
         eng.small_lanes = kw.get("lanes", "auto")
