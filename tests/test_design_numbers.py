@@ -1,11 +1,11 @@
-"""Every number DESIGN.md (the design as built, round 5) quotes from a tracked JSON file must be IN that file.
+"""Every number DESIGN.md (the design as built, round 6) quotes from a tracked JSON file must be IN that file.
 
 A cell that quotes a measurement writes it as   **number** (`file.json[key].field.sub` / scale)   — the bold number, then in
-backticks the tracked file (under profiles/r05/, then profiles/), an optional top-level [key] (keys of valu.json / traffic.json
+backticks the tracked file (under profiles/r06/, then profiles/), an optional top-level [key] (keys of valu.json / traffic.json
 contain ':' and ','), a dotted path, and an optional '/ scale' or 'x scale'.  This test parses all of them and fails on a
 mismatch beyond the rounding of the printed digits (plus 0.2 %), so that the document cannot drift from the files the way
 round 2's did (391 vs 374.4 VALU per wave-step).  It also pins profiles/valu.json and profiles/traffic.json — the copies
-bench.py reads — to the round's collection under profiles/r05/.  (profiles/r03/NOTES.md, round 3's text, was held to the same
+bench.py reads — to the round's collection under profiles/r06/.  (profiles/r03/NOTES.md, round 3's text, was held to the same
 rule until the per-round copies of the counter files it cites were pruned in round 5; it is frozen history.)"""
 import json
 import os
@@ -18,7 +18,7 @@ CITE = re.compile(r"\*\*(?P<num>[-+]?[0-9][0-9.,]*(?:e[-+]?[0-9]+)?)\*\*[^`|\n]{
 LOOSE = re.compile(r"\*\*[-+]?[0-9][0-9.,e+-]*\*\*[^`|\n]{0,60}?\(`[A-Za-z0-9_./-]+\.json")
 
 
-DOCS = {"DESIGN.md": (os.path.join("profiles", "r05"), "profiles")}
+DOCS = {"DESIGN.md": (os.path.join("profiles", "r06"), "profiles")}
 
 
 def _resolve(name, bases):
@@ -81,8 +81,8 @@ def test_document_numbers_are_in_the_files_they_cite(doc):
 
 def test_bench_reads_this_rounds_counter_files():
     for name in ("valu.json", "traffic.json"):
-        with open(os.path.join(ROOT, "profiles", name)) as a, open(os.path.join(ROOT, "profiles", "r05", name)) as b:
-            assert json.load(a) == json.load(b), f"profiles/{name} is not profiles/r05/{name}"
+        with open(os.path.join(ROOT, "profiles", name)) as a, open(os.path.join(ROOT, "profiles", "r06", name)) as b:
+            assert json.load(a) == json.load(b), f"profiles/{name} is not profiles/r06/{name}"
 
 
 def test_design_md_stays_a_design_document():

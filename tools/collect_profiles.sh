@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: produces every measurement DESIGN.md quotes
-# under gpurun_out/<tag>/.  Usage: bash tools/collect_profiles.sh r05 [quick|rest|sweeps]
+# under gpurun_out/<tag>/.  Usage: bash tools/collect_profiles.sh r06 [quick|rest|sweeps]
 # (quick = the default bench line, the kernel trace and every PMC pass; rest = the other bench lines and the sweeps)
 # rocprofv3 is always given the program itself after `--` (python3 script), never a shell or env wrapper, and the
 # --pmc passes carry --kernel-trace only (no sys/hip/hsa trace domains).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
@@ -37,6 +37,10 @@ timeout -k 10 400 rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OU
 SQC="SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_CVT"
 timeout -k 10 400 rocprofv3 --pmc $SQC --kernel-trace --output-format csv -d $OUT/pmc_sqc_fused32 -- python3 $R/tools/pmc_workload_fused.py 4000000 f32 96 > $OUT/pmc_sqc_fused32.log 2>&1
 python3 $R/tools/pmc_valu.py $OUT/sq_counters_f32_4M.csv $OUT/valu.json 96 $OUT/pmc_sqa_fused32 $OUT/pmc_sqb_fused32 $OUT/pmc_sqc_fused32 > /dev/null
+# the compensated fp32 form of the fused kernel (round 6): its own instruction stream
+timeout -k 10 400 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_fused32c -- python3 $R/tools/pmc_workload_fused.py 4000000 f32 96 multigas comp > $OUT/pmc_sqa_fused32c.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc $SQC --kernel-trace --output-format csv -d $OUT/pmc_sqc_fused32c -- python3 $R/tools/pmc_workload_fused.py 4000000 f32 96 multigas comp > $OUT/pmc_sqc_fused32c.log 2>&1
+python3 $R/tools/pmc_valu.py $OUT/sq_counters_f32_4M_compensated.csv $OUT/valu.json 96 $OUT/pmc_sqa_fused32c $OUT/pmc_sqc_fused32c > /dev/null
 # the other kernels bench.py can be asked to price: fp32 per-step (config 5), CO2-only (config 2)
 timeout -k 10 400 rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/pmc_sqa_step32 -- python3 $R/tools/pmc_workload.py 4000000 multigas f32 > $OUT/pmc_sqa_step32.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc $SQC --kernel-trace --output-format csv -d $OUT/pmc_sqc_step32 -- python3 $R/tools/pmc_workload.py 4000000 multigas f32 > $OUT/pmc_sqc_step32.log 2>&1

@@ -50,6 +50,12 @@ def main():
         ms = re.match(r"fiveeq::small_kernel<(double|float), (\d), (\d), false>", k)      # <T, P0, lanes per member, STATS>
         m = re.match(r"fiveeq::(step|fused)_kernel<(double|float2|float), (\d), (\d), (\d)((?:, (?:true|false))*)>", k)
         mm_ = re.match(r"fiveeq::small_multi_kernel<(double|float), (\d), (\d), (\d), false>", k)   # several gases: one lane per member
+        mo = re.match(r"fiveeq::small_octet_kernel<(double|float)>", k)                             # 4 + 1 + 1: one member per octet of lanes
+        comp = m is not None and m.group(1) == "fused" and m.group(6).replace(" ", "") == ",false,false,true"      # the compensated fp32 form
+        if mo:
+            m = re.match(r"(small) (\w+) (\d) (\d) (\d)()", f"small {mo.group(1)} 4 1 1")
+        if comp:
+            m = re.match(r"(fused) (\w+) (\d) (\d) (\d)()", f"fused {m.group(2)} {m.group(3)} {m.group(4)} {m.group(5)}")
         if ms:
             m = re.match(r"(small) (\w+) (\d) (0) (0)()", f"small {ms.group(1)} {ms.group(2)} 0 0")
         if mm_:
@@ -69,6 +75,11 @@ def main():
             key += f":{ms.group(3)}"
         if mm_:
             key += ":1"
+        if mo:
+            per_wave = 8
+            key += ":8"
+        if comp:
+            key += ":comp"
         rec = {"kernel": k, "valu_per_wave_step": valu / waves / steps, "members_per_wave": per_wave,
                "valu_per_member_step": valu / waves / steps / per_wave, "waves": waves, "steps_per_launch": steps,
                "dispatches": len(acc[(k, "SQ_INSTS_VALU")])}
