@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fiveeqscm_amd import emissions, params, scenario  # noqa: E402
+from fiveeqscm_amd import emissions, hostbind, params, scenario  # noqa: E402
 from fiveeqscm_amd.distributed import shard_bounds  # noqa: E402
 from fiveeqscm_amd.engine import EnsembleEngine  # noqa: E402
 
@@ -35,6 +35,8 @@ def main():
     for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
         os.environ.setdefault(key, val)                            # started without a launcher: a one-rank job
     rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    # this rank's host thread next to its GPU (sysfs, applied before anything touches the GPU; no wrapper, no re-exec)
+    hostbind.bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     dev = torch.device(f"cuda:{local % torch.cuda.device_count()}")
     torch.cuda.set_device(dev)
     if a.backend == "nccl":
