@@ -86,6 +86,7 @@ def test_bench_reads_this_rounds_counter_files():
 
 
 def test_design_md_stays_a_design_document():
-    """The design as built in at most 24 KB (review, round 3: 59 KB, half of it A/B history — that lives in profiles/r0N/ now;
-    round 5 added the small-ensemble kernel and what the N > 1 line carries, and moved the cap from 20 to 24 KB)."""
-    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 24 * 1024
+    """The design as built in at most 28 KB (review, round 3: 59 KB, half of it A/B history — that lives in profiles/r0N/ now;
+    round 5 added the small-ensemble kernel and what the N > 1 line carries: 20 -> 24 KB; round 6 the compensated fp32 form, the
+    octet kernel, the placement finding and the host binding: 24 -> 28 KB)."""
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 28 * 1024
