@@ -146,10 +146,11 @@ def regime(resident_bytes, n_seq=1):
     """Where the rows of one launch live between two launches: the label that goes beside `frac` (a fraction of the HBM PEAK is
     an HBM fraction only when the bytes cross HBM)."""
     mb, share = resident_bytes / 1e6, resident_bytes / INFINITY_CACHE
+    if n_seq > 1:
+        return (f"chunk-major ({mb:.0f} MB per chunk, {share:.2f} of the Infinity Cache: each chunk's rows stay cached between its launches, "
+                f"{n_seq} chunks one after the other)")
     if share <= 0.8:
         return f"infinity-cache-resident ({mb:.0f} MB of state + parameters in the 256 MiB Infinity Cache; hbm_resident_frac is the HBM-true figure)"
-    if n_seq > 1:
-        return f"chunk-major ({mb:.0f} MB per chunk, {share:.2f} of the Infinity Cache: each chunk's rows stay cached between its launches)"
     return f"hbm-streamed ({mb:.0f} MB of state + parameters per launch, {share:.1f}x the 256 MiB Infinity Cache)"
 
 

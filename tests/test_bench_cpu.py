@@ -38,3 +38,18 @@ def test_launcher_environment_is_not_relaunched():
     finally:
         os.environ.clear()
         os.environ.update(env_backup)
+
+
+def test_roofline_regime_labels_and_key_order():
+    """benchlib/legs.py pieces that need no GPU: the regime label that goes beside `roofline.frac` (a fraction of the HBM PEAK is
+    an HBM fraction only when the bytes cross HBM) and the order of the roofline object (the driver's parser keeps the head)."""
+    sys.path.insert(0, ROOT)
+    from benchlib import legs
+    assert legs.regime(152e6).startswith("infinity-cache-resident (152 MB")
+    assert legs.regime(8 * 19 * 8_000_000).startswith("hbm-streamed (1216 MB") and "4.5x" in legs.regime(8 * 19 * 8_000_000)
+    assert legs.regime(180e6, n_seq=14).startswith("chunk-major (180 MB per chunk, 0.67 of the Infinity Cache")
+    assert legs.regime(230e6).startswith("hbm-streamed")                     # past 0.8 of the cache without chunking
+    r = legs.ordered({"note": 1, "kernel": "k", "hbm_resident_frac": 0.8, "regime": "x", "frac": 0.9, "traffic": None, "unit": "GB/s",
+                      "peak": 8000.0, "achieved": 7200.0, "bound": "hbm", "single_launch_frac": 0.85, "zzz": 0})
+    assert list(r)[:9] == ["bound", "achieved", "peak", "unit", "frac", "regime", "traffic", "hbm_resident_frac", "single_launch_frac"]
+    assert list(r)[-2:] == ["note", "zzz"] and len(r) == 12

@@ -194,6 +194,17 @@ def test_new_entry_points_validate_on_the_host():
     common = (ctypes.byref(m), 8, 8, p, 4, 0, 4, p, p, p, p, None, None, 0, None)
     assert lib.fiveeq_run_ksteps_f64(*common, 0, None) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
     assert lib.fiveeq_run_ksteps_f32(*common, -3, None) == _capi.E_INVALID
+    # the compensated fp32 form (ABI v11): the arguments of run_ksteps + run_fused_bins in one entry point; bin_ring = NULL: no ring
+    comp = lambda k, lo=0.0, hi=1.0, nb=1, ring=None, rows=0, t0=0, t1=4: lib.fiveeq_run_fused_comp_f32(   # noqa: E731
+        ctypes.byref(m), 8, 8, p, 4, t0, t1, p, p, p, p, None, None, 0, None, k, lo, hi, nb, ring, rows, None)
+    assert comp(0) == _capi.E_INVALID and b"k_steps" in lib.fiveeq_last_error()
+    assert comp(4, t0=2, t1=2) == _capi.OK                                    # an empty range: validated, nothing launched
+    assert comp(4, 1.0, 1.0, 8, p, 4) == _capi.E_INVALID and b"lo < hi" in lib.fiveeq_last_error()
+    assert comp(4, 0.0, 1.0, 5000, p, 4) == _capi.E_INVALID and b"n_bins" in lib.fiveeq_last_error()
+    assert comp(4, 0.0, 1.0, 8, p, 0) == _capi.E_INVALID and b"ring_rows" in lib.fiveeq_last_error()
+    assert comp(4, 0.0, 1.0, 8, ctypes.c_void_p(0x1001), 4) == _capi.E_INVALID and b"aligned" in lib.fiveeq_last_error()
+    assert comp(4, 0.0, 1.0, 8, p, 4, t0=3, t1=3) == _capi.OK
+    assert lib.fiveeq_run_fused_comp_f32(None, 8, 8, p, 4, 0, 4, p, p, p, p, None, None, 0, None, 4, 0.0, 1.0, 1, None, 0, None) == _capi.E_INVALID
     # the small-ensemble kernels: 4 lanes per member for a lone 4-pool gas, 8 for 4 + 1 + 1, 1 for every other compiled layout
     lanes = lambda *pl: lib.fiveeq_small_lanes(len(pl), (ctypes.c_int32 * len(pl))(*pl))   # noqa: E731
     assert [lanes(4), lanes(1), lanes(2), lanes(3), lanes(4, 1, 1), lanes(1, 1), lanes(4, 4, 4), lanes(5), lanes(2, 3)] == [4, 1, 1, 1, 8, 1, 1, 0, 0]

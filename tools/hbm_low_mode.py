@@ -12,12 +12,10 @@ of the process.  This tool measures, in ONE process and as often as asked:
 
 One JSON line per cycle on stdout.  --tag goes into every line (the shell loop's run index)."""
 import argparse
-import ctypes
 import glob
 import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch
