@@ -762,7 +762,8 @@ def test_random_models_and_scenarios_match_oracle(gpu):
         if not (np.all(np.isfinite(want["C"])) and np.all(np.isfinite(want["T"]))):
             continue                                                   # a draw the model itself cannot digest
         first = None
-        for mode, lanes in (("per_step", "auto"), ("fused", "auto"), ("small", 1)) + ((("small", 4),) if pools == [4] else ()):
+        for mode, lanes in ((("per_step", "auto"), ("fused", "auto"), ("small", 1)) + ((("small", 4),) if pools == [4] else ())
+                            + ((("small", 8),) if pools == [4, 1, 1] else ())):
             eng = _engine(p, N, E, F_ext=F_ext, dt=dt, small_lanes=lanes)
             eng.run(mode=mode)
             torch.cuda.synchronize()
