@@ -136,7 +136,10 @@ def main():
     # ---- this rank's host thread goes next to its GPU — read from sysfs and applied BEFORE anything touches the GPU (no wrapper,
     # no re-exec; the HIP runtime's helper threads inherit the mask); checked against the runtime's own PCI address below -----
     from fiveeqscm_amd import hostbind
-    binding = hostbind.bind_rank(local_rank, local_world)
+    try:
+        binding = hostbind.bind_rank(local_rank, local_world)
+    except Exception as exc:  # noqa: BLE001 - a binding that cannot be worked out must never cost the measurement
+        binding = {"applied": False, "reason": f"{type(exc).__name__}: {exc}"}
 
     import torch
     from benchlib import legs
@@ -176,7 +179,10 @@ def main():
 
     props = torch.cuda.get_device_properties(dev)
     pci = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
-    binding = hostbind.verify(binding, pci, local_rank, local_world)
+    try:
+        binding = hostbind.verify(binding, pci, local_rank, local_world)
+    except Exception as exc:  # noqa: BLE001
+        binding = dict(binding, verify_error=f"{type(exc).__name__}: {exc}")
     devices = ctl.gather_over_ranks({"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": props.name,
                                      "pci_bus_id": pci, "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
                                      "visible_devices": torch.cuda.device_count(), "cpus": binding.get("cpus"),

@@ -36,7 +36,10 @@ def main():
         os.environ.setdefault(key, val)                            # started without a launcher: a one-rank job
     rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
     # this rank's host thread next to its GPU (sysfs, applied before anything touches the GPU; no wrapper, no re-exec)
-    hostbind.bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    try:
+        hostbind.bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    except Exception:  # noqa: BLE001 - an optimisation: never a reason not to run
+        pass
     dev = torch.device(f"cuda:{local % torch.cuda.device_count()}")
     torch.cuda.set_device(dev)
     if a.backend == "nccl":
