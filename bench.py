@@ -21,7 +21,8 @@ Rank 0 prints ONE JSON line.  `value` = (members on all GPUs) x K / the K-step b
 clocked once on the wall clock (barrier, device sync, clock, K steps, drain, clock: `timing.first_block_ms_per_step`) and then
 repeated back to back for --timed-s (6.5) seconds of device time, HIP event to HIP event; the MEDIAN block is reported.
 `timing.host_enqueue_us_per_step` / `host_share` say how long the rank's host thread needs to enqueue a step with all ranks
-enqueuing at once.  `roofline` prices the kernel of the chosen --mode: the per-step kernel against the
+enqueuing at once.  `roofline.traffic` (N = 1, per-step form) is MEASURED BY THE RUN ITSELF: two child `rocprofv3 --pmc` passes
+(FETCH_SIZE, WRITE_SIZE) of the same kernel at the same size before this process touches the GPU, calibrated on a known copy.  `roofline` prices the kernel of the chosen --mode: the per-step kernel against the
 8 TB/s HBM peak with the ALGORITHMIC bytes A = w(2 SP + 4 G + 7) = 248 B per member-step (plus the same
 kernel on an ensemble far beyond the Infinity Cache, `hbm_resident`, and its fp64 VALU issue fraction);
 the fused / K-step / small-ensemble kernels with their own A and bound "fp64-valu"; `roofline.single_launch_*` is the per-step
@@ -91,6 +92,9 @@ def parse():
     ap.add_argument("--compensated", action="store_true",
                     help="--dtype f32 --mode fused|ksteps only: the compensated fp32 form of the time-fused kernel (include/fiveeq.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two child rocprofv3 --pmc passes before the GPU is touched, "
+                         "N = 1 and the per-step form only): take the committed profiles/traffic.json figure, labelled as such")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the beyond-Infinity-Cache roofline leg")
     ap.add_argument("--hbm-resident-members", type=int, default=8_000_000)
     ap.add_argument("--hbm-placements", type=int, default=5,
@@ -132,6 +136,14 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(kind, G, a.cpu_sample_members, N_SCEN, numpy_legs=a.numpy_baseline)
+
+    # ---- roofline.traffic MEASURED IN THIS RUN (rank 0 of a one-GPU per-step run): two child `rocprofv3 --pmc` passes, FETCH_SIZE and
+    # WRITE_SIZE separately, of the same kernel at the same size (tools/pmc_workload.py), each calibrated on a known copy in the
+    # same pass — as child processes BEFORE this process touches the GPU ---------------------------------------------------
+    traffic_live = None
+    if (rank == 0 and world == 1 and not a.no_live_traffic and not a.no_trajectory and (a.mode or "per_step") in ("per_step", "graph")
+            and "rocprof" not in os.environ.get("LD_PRELOAD", "")):      # (not from inside a profiled process)
+        traffic_live = live_traffic(kind, a.dtype, per_gpu)
 
     # ---- this rank's host thread goes next to its GPU — read from sysfs and applied BEFORE anything touches the GPU (no wrapper,
     # no re-exec; the HIP runtime's helper threads inherit the mask); checked against the runtime's own PCI address below -----
@@ -334,6 +346,12 @@ def main():
     _, _, _, members_per_wave, _, packed = legs.kernel_tags(eng, a, n_local)
     if not fusedlike:
         roofline, k_avg, kkey = legs.per_step_roofline(eng, a, G, per_gpu, n_local, t_idx)
+        if traffic_live is not None and "hbm_bytes_per_launch" in traffic_live:
+            roofline["traffic_committed"] = roofline["traffic"]          # the figure of profiles/traffic.json, for comparison
+            roofline["traffic"], roofline["traffic_source"] = traffic_live["hbm_bytes_per_launch"], traffic_live["source"]
+            roofline["traffic_detail"] = {k: traffic_live[k] for k in ("fetch_bytes", "write_bytes", "step_dispatches", "copy_calibration", "seconds")}
+        elif traffic_live is not None:
+            roofline["traffic_live_error"] = traffic_live.get("error")
     else:
         roofline, k_avg, kkey, members_per_wave = legs.fused_roofline(eng, a, mode_run, k_steps, n_local)
     legs.add_valu_issue(roofline, a, kkey, k_avg, members_per_wave, packed, fusedlike)
@@ -487,6 +505,43 @@ def _self_launch():
         os.killpg(proc.pid, signal.SIGTERM)
         rc = 130
     sys.exit(rc)
+
+
+def live_traffic(kind, dtype, members, timeout_s=150):
+    """HBM bytes per launch of the per-step kernel from PMC counters, collected BY THIS RUN: `rocprofv3 --pmc FETCH_SIZE
+    --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate passes: the two do not fit one; no other trace domain), the
+    program directly after `--` (python3 tools/pmc_workload.py: five calibration copies of known byte count, then 60 timesteps of
+    this workload), reduced exactly like the committed figure (tools/pmc_traffic.py: the guide's gfx950 correction comes out of
+    the calibration on the copy).  Child processes of a process that has not touched the GPU.  {"hbm_bytes_per_launch", ...} or
+    {"error": ...}: a failure costs the line nothing but the live figure (the committed one is reported instead, labelled)."""
+    import shutil
+    import subprocess
+    import tempfile
+    t0 = time.perf_counter()
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    tmp = tempfile.mkdtemp(prefix="fiveeq_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", FIVEEQ_SIDE_STREAM_PROBE="0")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, counter), "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), str(members), kind, dtype]
+            out = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if out.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {counter} exited {out.returncode}: {out.stderr[-300:]}"}
+        rec = pmc_traffic.reduce(os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"), 1 << 27)
+        rec["seconds"] = time.perf_counter() - t0
+        rec["source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of "
+                         f"tools/pmc_workload.py {members} {kind} {dtype} as child processes before the GPU was touched, calibrated on the "
+                         "copy kernel of known byte count in the same pass (tools/pmc_traffic.py)")
+        return rec
+    except Exception as exc:  # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _numpy_worker(argv):

@@ -10,10 +10,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args, timed_s="0.05"):
+def _bench(*args, timed_s="0.05", live_traffic=False):
     """One plain `python bench.py ...` call.  --timed-s: these tests check the line, not the figure, so they clock 50 ms of
-    device time instead of the default 6.5 s (the driver-call test below keeps the default)."""
+    device time instead of the default 6.5 s (the driver-call test below keeps the default); the two rocprofv3 --pmc child passes
+    that measure roofline.traffic (25 s) run in the contract test only."""
     extra = [] if timed_s is None or "--timed-s" in args else ["--timed-s", timed_s]
+    extra += [] if live_traffic or "--no-live-traffic" in args else ["--no-live-traffic"]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, *extra], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -24,7 +26,7 @@ def _bench(*args, timed_s="0.05"):
 
 def test_default_mode_line_has_the_contract_keys():
     d = _bench("--steps", "60", "--warmup", "5", "--members", "300000", "--cpu-sample-members", "20000",
-               "--hbm-resident-members", "2000000", "--kernel-batches", "1")
+               "--hbm-resident-members", "2000000", "--kernel-batches", "1", live_traffic=True)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "summary"):
         assert key in d, key
@@ -67,7 +69,12 @@ def test_default_mode_line_has_the_contract_keys():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["numpy_nproc"]["processes"] >= 1 and c["c_port_openmp"]["value"] > 0 and c["numpy_1core"]["value"] > 0
     assert c["value"] == max(c["numpy_nproc"]["value"], c["c_port_openmp"]["value"])          # the stronger whole-box figure
-    assert r["traffic_source"] is None or "traffic.json" in r["traffic_source"]
+    # roofline.traffic is MEASURED BY THIS RUN: two child rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same kernel at the
+    # same size before the GPU was touched, calibrated on a known copy — within a few per cent of the algorithmic bytes per launch
+    assert r["traffic_source"].startswith("measured by this run: rocprofv3 --pmc FETCH_SIZE"), r.get("traffic_live_error")
+    assert 0.95 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.15 * r["algorithmic_bytes_per_launch"]
+    td = r["traffic_detail"]
+    assert td["step_dispatches"][0] >= 60 and td["copy_calibration"]["copy_dispatches"][0] >= 5 and td["seconds"] < 120
     assert d["timed_repeats"] == 1 or d["timing"]["wall_ms_per_step_over_all_repeats"] >= d["ms_per_step"] * 0.98
     t = d["timing"]
     assert t["device_s_clocked"] >= 0.05 and 0.0 < t["host_enqueue_us_per_step_min"] <= t["host_enqueue_us_per_step"]
@@ -95,7 +102,7 @@ def test_fused_family_lines_price_their_own_kernel():
 
 # ---- the N > 1 path: exactly what the driver launches on a multi-GPU node, rehearsed on the one GPU of the test box ----
 _SMALL = ("--steps", "20", "--warmup", "5", "--members", "200000", "--no-cpu-baseline", "--no-hbm-resident",
-          "--kernel-batches", "1", "--timed-s", "0.05")
+          "--kernel-batches", "1", "--timed-s", "0.05", "--no-live-traffic")
 _RANK_ENV = dict(FIVEEQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
 
 

@@ -44,7 +44,7 @@ python3 bench.py --no-cpu-baseline --no-hbm-resident --workload config5 --dtype 
 python3 bench.py > $OUT/bench_config3.json 2> $OUT/bench_config3.err; echo bench1
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_config3_driver_call_20_steps.json 2>/dev/null
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-hbm-resident > $OUT/bench_config3_under_rocprof.json 2> $OUT/trace.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-hbm-resident --no-live-traffic > $OUT/bench_config3_under_rocprof.json 2> $OUT/trace.err
 for k in kernel_stats domain_stats; do src=$(ls -t $OUT/trace/*/*_$k.csv 2>/dev/null | head -1); [ -n "$src" ] && cp "$src" $OUT/${k}_bench_config3.csv; done
 rm -rf $OUT/pmc_sq*_fused32 $OUT/pmc_sq*_fused32c $OUT/pmc_sq*_step32 $OUT/pmc_sq*_small* $OUT/trace
 ls $OUT

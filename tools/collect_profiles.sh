@@ -16,7 +16,7 @@ echo "== bench (default workload) =="
 python3 $R/bench.py > $OUT/bench_config3.json 2> $OUT/bench_config3.err || echo "bench failed"
 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_config3_driver_call_20_steps.json 2>/dev/null || echo "bench (20 steps) failed"
 echo "== bench under rocprofv3 --kernel-trace --stats =="
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-hbm-resident \
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-hbm-resident --no-live-traffic \
     > $OUT/bench_config3_under_rocprof.json 2> $OUT/trace.err || echo "trace failed"
 echo "== PMC passes: HBM traffic (FETCH_SIZE, WRITE_SIZE separately) =="
 for N in 1000000 8000000; do

@@ -34,19 +34,19 @@ def per_kernel(dirname, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
-def main():
-    fetch_dir, write_dir, copy_elems, key = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-    out_path = sys.argv[5] if len(sys.argv) > 5 else None
+def reduce(fetch_dir, write_dir, copy_elems, kernel=None):
+    """HBM bytes per launch of `kernel` (default: the step kernel) from a FETCH_SIZE pass and a WRITE_SIZE pass, each calibrated
+    on the copy kernel of known byte count in the same pass.  Raises KeyError when a pass holds no dispatch of either kernel."""
     global KERNEL
-    if len(sys.argv) > 6 and sys.argv[6] == "fused":
-        KERNEL = "fiveeq::fused_kernel"
+    if kernel is not None:
+        KERNEL = kernel
     f = per_kernel(fetch_dir, "FETCH_SIZE")
     w = per_kernel(write_dir, "WRITE_SIZE")
     known = copy_elems * 8.0
     f_raw, w_raw = f["step"][0] * 1024.0, w["step"][0] * 1024.0
     f_cal = known / (f["copy"][0] * 1024.0)
     w_cal = known / (w["copy"][0] * 1024.0)
-    rec = {
+    return {
         "fetch_bytes_raw": f_raw, "write_bytes_raw": w_raw,
         "copy_calibration": {"known_bytes_each_way": known, "fetch_counted": f["copy"][0] * 1024.0,
                              "write_counted": w["copy"][0] * 1024.0, "fetch_factor": f_cal, "write_factor": w_cal,
@@ -55,6 +55,12 @@ def main():
         "hbm_bytes_per_launch": f_raw * f_cal + w_raw * w_cal,
         "step_dispatches": [f["step"][1], w["step"][1]],
     }
+
+
+def main():
+    fetch_dir, write_dir, copy_elems, key = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    out_path = sys.argv[5] if len(sys.argv) > 5 else None
+    rec = reduce(fetch_dir, write_dir, copy_elems, "fiveeq::fused_kernel" if len(sys.argv) > 6 and sys.argv[6] == "fused" else None)
     print(json.dumps({key: rec}, indent=1))
     if out_path:
         doc = {}

@@ -17,7 +17,7 @@ echo "== (1) bench.py --gpus N over gloo ==" | tee $OUT/host_share_rehearsal.txt
 export FIVEEQ_BENCH_BACKEND=gloo
 for n in 1 2 4 5; do
   for mode in per_step graph; do
-    python3 bench.py --gpus $n --steps 20 --warmup 5 --timed-s 1.5 --no-cpu-baseline --no-hbm-resident --kernel-batches 1 \
+    python3 bench.py --gpus $n --steps 20 --warmup 5 --timed-s 1.5 --no-cpu-baseline --no-hbm-resident --no-live-traffic --kernel-batches 1 \
         --mode $mode > $OUT/host_share_n${n}_${mode}.json 2> $OUT/host_share_n${n}_${mode}.err || exit 1
     python3 - $OUT/host_share_n${n}_${mode}.json <<'PY' | tee -a $OUT/host_share_rehearsal.txt
 import json, sys
