@@ -507,7 +507,7 @@ def _self_launch():
     sys.exit(rc)
 
 
-def live_traffic(kind, dtype, members, timeout_s=150):
+def live_traffic(kind, dtype, members, timeout_s=240):
     """HBM bytes per launch of the per-step kernel from PMC counters, collected BY THIS RUN: `rocprofv3 --pmc FETCH_SIZE
     --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate passes: the two do not fit one; no other trace domain), the
     program directly after `--` (python3 tools/pmc_workload.py: five calibration copies of known byte count, then 60 timesteps of
