@@ -381,6 +381,25 @@ def test_compensated_fp32_form_against_50_digit_arithmetic(capsys):
             print(f"    {key[0]:9s} {key[1]:13s} C {eC:.2e}  T {eT:.2e}")
     for key, (eC, eT) in worst.items():
         assert eC <= 5e-7 and eT <= 3e-6, (key, eC, eT)
+    # outside the model's domain the form keeps the default form's guards (log term off, sqrt C := 0 for C <= 0): emissions
+    # negative enough to drive the square-root gases through zero — finite results, close to the default fp32 arithmetic and to fp64
+    pm, Nm = cases.members("multigas")
+    Eneg = cases.scenario("multigas").copy()
+    Eneg[60:] = -np.abs(Eneg[60:]) * 6.0 - np.array([8.0, 900.0, 30.0])
+    runs = {}
+    for label, kw in (("f64", dict(dtype=torch.float64)), ("f32", dict(dtype=torch.float32)),
+                      ("f32c", dict(dtype=torch.float32, compensated=True))):
+        eng = EnsembleEngine(pm, Nm, Eneg[:200], device="cuda:0", **kw)
+        eng.run(mode="fused")
+        torch.cuda.synchronize()
+        runs[label] = (eng.C.double().cpu().numpy(), eng.T.double().cpu().numpy())
+        eng.close()
+    assert (runs["f64"][0].min(axis=(0, 2))[1:] < 0).all()                                # CH4 and N2O did go through zero (CO2 to 80 ppm)
+    for label in ("f32", "f32c"):
+        assert np.isfinite(runs[label][0]).all() and np.isfinite(runs[label][1]).all()
+        scale_C = np.abs(runs["f64"][0]).max(axis=0, keepdims=True)
+        assert (np.abs(runs[label][0] - runs["f64"][0]) <= 2e-4 * scale_C).all(), label
+        assert (np.abs(runs[label][1] - runs["f64"][1]) <= 2e-4 * np.abs(runs["f64"][1]).max()).all(), label
     p, N = cases.members("co2")
     with pytest.raises(ValueError):
         EnsembleEngine(p, N, cases.scenario("co2"), device="cuda:0", compensated=True)                      # fp64 does not need it
