@@ -50,7 +50,7 @@ def test_bench_numpy_worker_runs_without_torch_or_gpu():
 
 def test_pmc_traffic_reducer_on_a_synthetic_counter_table(tmp_path):
     """tools/pmc_traffic.reduce — the reducer behind profiles/traffic.json AND behind the traffic figure bench.py measures itself
-    (bench.live_traffic) — on a hand-made rocprofv3 counter table: KiB units, the calibration on the copy kernel of known byte
+    (benchlib.traffic.live_traffic) — on a hand-made rocprofv3 counter table: KiB units, the calibration on the copy kernel of known byte
     count in the same pass (which is where the guide's gfx950 FETCH_SIZE correction comes from), means over dispatches."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
