@@ -96,6 +96,7 @@ SIGNATURES = {
     "fiveeq_run_small_f64": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
     "fiveeq_run_small_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, _p]),
     "fiveeq_run_fused_comp_f32": (ctypes.c_int, _RUN_ARGS[:-1] + [_i32, ctypes.c_double, ctypes.c_double, _i32, _p, _i32, _p]),
+    "fiveeq_run_small_comp_f32": (ctypes.c_int, _RUN_ARGS),
     "fiveeq_small_lanes": (_i32, [_i32, ctypes.POINTER(_i32)]),
     "fiveeq_set_f32_packing": (ctypes.c_int, [ctypes.c_int]),
     "fiveeq_set_row_policy": (ctypes.c_int, [_i32]),

@@ -456,6 +456,36 @@ int run_small(const fiveeq_model* m, int64_t n, int64_t ld, const T* drive, int3
     return FIVEEQ_OK;
 }
 
+// ---- the compensated fp32 form on the small-ensemble kernel: one member per lane, every layout ----
+int run_small_comp(const fiveeq_model* m, int64_t n, int64_t ld, const float* drive, int32_t n_steps, int32_t t_begin,
+                   int32_t t_end, const float* r, const float* q, float* R, float* S, float* C_traj, float* T_traj, int n_rows,
+                   double* stats, void* stream) {
+    RunArgs<float> a;
+    if (int rc = make_args(a, m, n, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, stats)) return rc;
+    if (t_begin == t_end) return FIVEEQ_OK;
+    const int64_t blocks = (a.n + FIVEEQ_SMALL_BLOCK - 1) / FIVEEQ_SMALL_BLOCK;
+    if (blocks > 0x7fffffffLL) return fail(FIVEEQ_E_INVALID, "n_members too large for one launch");
+    const dim3 grid((unsigned)blocks), block(FIVEEQ_SMALL_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    const bool st_on = a.stats != nullptr;
+    switch (a.code) {
+#define X(p0, p1, p2)                                                                                                          \
+    case (p0) * 100 + (p1) * 10 + (p2):                                                                                        \
+        if (st_on)                                                                                                             \
+            hipLaunchKernelGGL((small_multi_kernel<float, p0, p1, p2, true, true>), grid, block, 0, st, a.km, a.drive, a.n_steps,  \
+                               t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);          \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((small_multi_kernel<float, p0, p1, p2, false, true>), grid, block, 0, st, a.km, a.drive, a.n_steps, \
+                               t_begin, t_end, a.n, a.ld, a.r, a.q, a.R, a.S, a.C_traj, a.T_traj, a.n_rows, a.stats);          \
+        break;
+        FIVEEQ_LAYOUTS(X)
+#undef X
+        default: return fail(FIVEEQ_E_UNSUPPORTED, "pool layout %03d has no compiled kernel", a.code);
+    }
+    HIP_TRY(hipGetLastError());
+    return FIVEEQ_OK;
+}
+
 // ---- plans: the per-step launch sequence captured into a hipGraph --------------------------
 struct Plan {
     uint32_t magic;
@@ -679,6 +709,11 @@ int fiveeq_run_small_f32(const fiveeq_model* model, int64_t n_members, int64_t l
                          void* stream) {
     return run_small<float>(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats,
                             lanes_per_member, stream);
+}
+int fiveeq_run_small_comp_f32(const fiveeq_model* model, int64_t n_members, int64_t ld, const float* drive, int32_t n_steps,
+                              int32_t t_begin, int32_t t_end, const float* r, const float* q, float* R, float* S, float* C_traj,
+                              float* T_traj, int32_t n_rows, double* T_stats, void* stream) {
+    return run_small_comp(model, n_members, ld, drive, n_steps, t_begin, t_end, r, q, R, S, C_traj, T_traj, n_rows, T_stats, stream);
 }
 int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t* n_pools) {
     if (!fiveeq_layout_supported(n_gas, n_pools)) return 0;

@@ -1264,7 +1264,10 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
 // three gases fit beside the state) and on a drive record held in registers and read one step ahead.  What a launch-bound
 // multi-gas ensemble gains over the fused kernel is the LDS round trips per step that nothing hides when a wave is alone on
 // its SIMD.  (A quad per gas would carry 4 members per wave: worth it below ~4k members only; not built.)
-template <typename T, int P0, int P1, int P2, bool STATS>
+// COMP = true (fp32 only): the compensated form of gas_step (a compensation word per pool in registers, the forcing from the excess
+// C - C0) on this kernel — what a launch-bound fp32 ensemble takes under EnsembleEngine(compensated=True); every layout, the
+// single-gas ones included (fiveeq_run_small_comp_f32).
+template <typename T, int P0, int P1, int P2, bool STATS, bool COMP = false>
 __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void small_multi_kernel(
     const KModel<T> km, const T* __restrict__ drive, const int n_steps, const int t_begin, const int t_end,
     const int64_t n, const int64_t ld, const T* __restrict__ r, const T* __restrict__ q, T* __restrict__ R,
@@ -1298,6 +1301,11 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
     const bool active = m < n;
     const int64_t mm = active ? m : 0;
     T rr[3 * L::G], qq[2], Rv[L::SP], Sv[2], Cv[L::G], Tn;
+    T Rlo[L::SP], no_cum[L::G];                                          // COMP: the compensation words (zero at launch)
+    if constexpr (COMP) {
+#pragma unroll
+        for (int k = 0; k < L::SP; ++k) Rlo[k] = T(0);
+    }
 #pragma unroll
     for (int k = 0; k < L::SP; ++k) Rv[k] = R[k * ld + mm];
 #pragma unroll
@@ -1325,7 +1333,7 @@ __global__ __launch_bounds__(FIVEEQ_SMALL_BLOCK) __attribute__((amdgpu_waves_per
 #pragma unroll
             for (int j = 0; j < DRIVE_STRIDE - 1; ++j) nxt[j] = drv[kn * DRIVE_STRIDE + j];
             const int rowvn = row_s[kn];
-            member_step<T, L>(kl, cur, rr, qq, Rv, Sv, Cv, Tn);
+            member_step<T, L, false, COMP>(kl, cur, rr, qq, Rv, Sv, Cv, Tn, no_cum, Rlo);
             const int row = __builtin_amdgcn_readfirstlane(rowv);
             if (row >= 0 && row < n_rows && active) {
                 if (C_traj != nullptr) {

@@ -130,7 +130,8 @@ class EnsembleEngine(CheckpointMixin):
         (include/fiveeq.h, fiveeq_run_fused_comp_f32): every pool carries the rounding error of its own update in a second
         register word (no HBM bytes) and the forcing is computed from the excess C - C0 — worst error against 50-digit
         arithmetic C 2.9e-6 -> 1.8e-7, T 1.7e-5 -> 7e-7.  Its own arithmetic: not bit-identical to the default forms; the modes
-        that keep the state in HBM between launches ('per_step', 'graph') and the small-ensemble kernels refuse it.
+        that keep the state in HBM between launches ('per_step', 'graph') refuse it; mode 'small' runs it one member per lane
+        (fiveeq_run_small_comp_f32), which is what 'auto' takes for a launch-bound ensemble.
         small_lanes: mode='small' (no in-loop histograms): lanes per member, 4 (a lone 4-pool gas: one pool per lane of a
         quad), 8 (the 4 + 1 + 1 layout: one pool per lane of an octet; no collect_stats), 1 (any layout), or "auto" = the widest
         form the layout has while the ensemble is small enough for it (SMALL_*_MEMBERS_PER_CU), else 1."""
@@ -284,6 +285,8 @@ class EnsembleEngine(CheckpointMixin):
         wants in-loop histograms or the concentration-driven form."""
         if not self.small_widest or self.T_hist is not None or self.concentration_driven:
             return 0
+        if self.compensated:                                     # fiveeq_run_small_comp_f32: one member per lane, every layout
+            return 1 if self.small_lanes in ("auto", 1) else 0
         octet_ok = self.small_widest == 8 and not self.collect_stats       # the octet form writes no per-wave statistics
         if self.small_lanes != "auto":
             if self.small_lanes == 8:
@@ -303,8 +306,9 @@ class EnsembleEngine(CheckpointMixin):
         there: profiles/r04/auto_hist_table.txt); an explicit k_steps, or a run the small kernel does not serve, 'ksteps'."""
         if mode != "auto":
             return mode, k_steps
-        if self.compensated:                                     # the compensation words live in registers: the time-fused kernel
-            return "fused", None
+        if self.compensated:                                     # the compensation words live in registers: the time-fused kernel,
+            launch_bound = (self.auto_k_steps() if k_steps is None else int(k_steps)) > 1     # or the small-ensemble one (one lane)
+            return ("small" if launch_bound and k_steps is None and self.small_form() else "fused"), None
         k = self.auto_k_steps() if k_steps is None else int(k_steps)
         if k <= 1:
             return "per_step", None
@@ -416,9 +420,9 @@ class EnsembleEngine(CheckpointMixin):
             raise ValueError(f"unknown mode {mode!r}")
         if self.T_hist is not None and mode not in ("fused", "per_step"):
             raise ValueError(f"mode {mode!r} does not fill T_hist: use 'fused' or 'per_step' with hist=")
-        if self.compensated and mode not in ("fused", "ksteps"):
+        if self.compensated and mode not in ("fused", "ksteps", "small"):
             raise ValueError(f"mode {mode!r} has no compensated form: the compensation words live in registers, so only the "
-                             "time-fused kernel ('fused', 'ksteps') carries them")
+                             "time-fused kernel ('fused', 'ksteps') and the small-ensemble kernel ('small', one lane) carry them")
         if mode == "small" and not self.small_form():
             raise ValueError("mode 'small' serves runs without in-loop histograms or the inverse form, with 4 lanes per "
                              "member for a lone 4-pool gas only and 8 for pools [4, 1, 1] without collect_stats "
@@ -434,6 +438,8 @@ class EnsembleEngine(CheckpointMixin):
                 rc = self._run_per_step(t_begin, t_end, stream, join)
             elif mode == "fused" and self.T_hist is not None:
                 rc = self._run_fused_bin_ring(t_begin, t_end, stream)
+            elif self.compensated and mode == "small":
+                rc = self.lib.fiveeq_run_small_comp_f32(*self._run_args(t_begin, t_end), self._stream(stream))
             elif self.compensated:                                   # 'fused' / 'ksteps' without a ring: one C call
                 span = (self.fused_span_steps(t_end - t_begin) if mode == "fused" else
                         max(self.auto_k_steps() if k_steps is None else int(k_steps), 1))

@@ -248,6 +248,13 @@ int fiveeq_run_fused_comp_f32(const fiveeq_model *model, int64_t n_members, int6
                               const float *r, const float *q, float *R, float *S,
                               float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, int32_t k_steps,
                               double lo, double hi, int32_t n_bins, uint16_t *bin_ring, int32_t ring_rows, void *stream);
+/* new (ABI v11) — the same compensated arithmetic on the SMALL-ENSEMBLE kernel (one member per lane, the model in registers; every
+ * compiled layout): what a launch-bound fp32 ensemble takes instead of the fused kernel (10k three-gas members: about half the
+ * time per step).  One launch for the whole span; arguments of fiveeq_run_fused_f32; the words are dropped at the end of the call. */
+int fiveeq_run_small_comp_f32(const fiveeq_model *model, int64_t n_members, int64_t ld,
+                              const float *drive, int32_t n_steps, int32_t t_begin, int32_t t_end,
+                              const float *r, const float *q, float *R, float *S,
+                              float *C_traj, float *T_traj, int32_t n_rows, double *T_stats, void *stream);
 /* lanes per member of the widest small-ensemble form compiled for (n_gas, n_pools[]): 4 (a lone 4-pool gas), 8 (4 + 1 + 1),
  * 1 (every other compiled layout), or 0 = the layout has no kernel at all */
 int32_t fiveeq_small_lanes(int32_t n_gas, const int32_t *n_pools);

@@ -205,6 +205,8 @@ def test_new_entry_points_validate_on_the_host():
     assert comp(4, 0.0, 1.0, 8, ctypes.c_void_p(0x1001), 4) == _capi.E_INVALID and b"aligned" in lib.fiveeq_last_error()
     assert comp(4, 0.0, 1.0, 8, p, 4, t0=3, t1=3) == _capi.OK
     assert lib.fiveeq_run_fused_comp_f32(None, 8, 8, p, 4, 0, 4, p, p, p, p, None, None, 0, None, 4, 0.0, 1.0, 1, None, 0, None) == _capi.E_INVALID
+    small_comp = lambda t0, t1, Rp=p: lib.fiveeq_run_small_comp_f32(ctypes.byref(m), 8, 8, p, 4, t0, t1, p, p, Rp, p, None, None, 0, None, None)   # noqa: E731
+    assert small_comp(2, 2) == _capi.OK and small_comp(0, 4, None) == _capi.E_INVALID and small_comp(3, 2) == _capi.E_INVALID
     # the small-ensemble kernels: 4 lanes per member for a lone 4-pool gas, 8 for 4 + 1 + 1, 1 for every other compiled layout
     lanes = lambda *pl: lib.fiveeq_small_lanes(len(pl), (ctypes.c_int32 * len(pl))(*pl))   # noqa: E731
     assert [lanes(4), lanes(1), lanes(2), lanes(3), lanes(4, 1, 1), lanes(1, 1), lanes(4, 4, 4), lanes(5), lanes(2, 3)] == [4, 1, 1, 1, 8, 1, 1, 0, 0]

@@ -337,7 +337,8 @@ def test_compensated_fp32_form_against_50_digit_arithmetic(capsys):
     C - C0 — against the 50-digit reference over all 24 golden members and 750 steps: C within 5e-7, T within 3e-6
     (relative, 1e-2 K floor); the default fp32 arithmetic is at 2.9e-6 / 1.7e-5 (the test above).  One launch, relaunched every
     128 steps (the words are dropped at launch boundaries: at most one rounding per word and launch), K steps per launch, with the
-    streamed histograms, packed and scalar lanes (bit-identical to each other); and what the form refuses."""
+    streamed histograms, packed and scalar lanes (bit-identical to each other), the small-ensemble kernel (one member per lane:
+    the fused kernel's bits; what 'auto' takes for a launch-bound ensemble); and what the form refuses."""
     torch = pytest.importorskip("torch")
     from fiveeqscm_amd import _capi
     from fiveeqscm_amd.engine import EnsembleEngine
@@ -349,7 +350,8 @@ def test_compensated_fp32_form_against_50_digit_arithmetic(capsys):
         runs = {}
         for label, kw, mode, k in (("one launch", dict(fused_span=None), "fused", None), ("span 128", dict(fused_span=128), "fused", None),
                                    ("ksteps 50", {}, "ksteps", 50), ("with hist", dict(hist=(-1.0, 8.0, 1024), hist_ring_steps=64), "fused", None),
-                                   ("scalar lanes", dict(fused_span=None), "fused", None)):
+                                   ("scalar lanes", dict(fused_span=None), "fused", None),
+                                   ("small 1 lane", {}, "small", None), ("auto", {}, "auto", None)):
             prev = lib.fiveeq_set_f32_packing(0) if label == "scalar lanes" else None
             try:
                 eng = EnsembleEngine(p, N, cases.scenario(kind), dtype=torch.float32, device="cuda:0", output_steps=cases.STEPS,
@@ -359,6 +361,7 @@ def test_compensated_fp32_form_against_50_digit_arithmetic(capsys):
             finally:
                 if prev is not None:
                     lib.fiveeq_set_f32_packing(prev)
+            assert label != "auto" or eng.last_mode == "small"        # 24 members are launch-bound: the small-ensemble kernel
             C, T = eng.C.double().cpu().numpy(), eng.T.double().cpu().numpy()
             runs[label] = (eng.C.clone(), eng.T.clone())
             if label == "with hist":
@@ -372,6 +375,9 @@ def test_compensated_fp32_form_against_50_digit_arithmetic(capsys):
             worst[(kind, label)] = (eC, eT)
             eng.close()
         assert torch.equal(runs["one launch"][0], runs["scalar lanes"][0]) and torch.equal(runs["one launch"][1], runs["scalar lanes"][1])
+        # one launch of the small-ensemble kernel = the same compensated member_step() on the same values: the fused kernel's bits
+        assert torch.equal(runs["small 1 lane"][0], runs["one launch"][0]) and torch.equal(runs["small 1 lane"][1], runs["one launch"][1])
+        assert torch.equal(runs["auto"][0], runs["small 1 lane"][0])
         # (the relaunched forms drop the words at their launch boundaries: close to the one-launch run, not equal to it)
         assert not torch.equal(runs["one launch"][0], runs["ksteps 50"][0])
         assert (runs["one launch"][0] - runs["ksteps 50"][0]).abs().max() <= 4e-7 * runs["one launch"][0].abs().max()
@@ -403,9 +409,17 @@ def test_compensated_fp32_form_against_50_digit_arithmetic(capsys):
     p, N = cases.members("co2")
     with pytest.raises(ValueError):
         EnsembleEngine(p, N, cases.scenario("co2"), device="cuda:0", compensated=True)                      # fp64 does not need it
+    from fiveeqscm_amd import params as prm_
+    params_big = prm_.sample_ensemble_shard(prm_.default_params("co2"), 2_000_000, device="cuda:0", dtype=torch.float32)
     eng = EnsembleEngine(p, N, cases.scenario("co2"), dtype=torch.float32, device="cuda:0", compensated=True)
-    assert eng.resolve_mode("auto")[0] == "fused"
-    for mode in ("per_step", "graph", "small"):
+    assert eng.resolve_mode("auto")[0] == "small" and eng.small_form() == 1       # launch-bound: one member per lane
+    big = EnsembleEngine(params_big, 2_000_000, cases.scenario("co2"), dtype=torch.float32, device="cuda:0", compensated=True,
+                         store_trajectory=False)
+    assert big.resolve_mode("auto")[0] == "fused"
+    big.close()
+    for mode in ("per_step", "graph"):
         with pytest.raises(ValueError):
             eng.run(mode=mode)
+    with pytest.raises(ValueError):
+        EnsembleEngine(p, N, cases.scenario("co2"), dtype=torch.float32, device="cuda:0", compensated=True, small_lanes=4).run(mode="small")
     eng.close()
