@@ -49,7 +49,7 @@ def main():
         # fused_kernel<V, P0, P1, P2, INV, BINS>: the plain forward form only
         ms = re.match(r"fiveeq::small_kernel<(double|float), (\d), (\d), false>", k)      # <T, P0, lanes per member, STATS>
         m = re.match(r"fiveeq::(step|fused)_kernel<(double|float2|float), (\d), (\d), (\d)((?:, (?:true|false))*)>", k)
-        mm_ = re.match(r"fiveeq::small_multi_kernel<(double|float), (\d), (\d), (\d), false>", k)   # several gases: one lane per member
+        mm_ = re.match(r"fiveeq::small_multi_kernel<(double|float), (\d), (\d), (\d), false(?:, false)?>", k)   # one lane per member (<.., STATS, COMP>)
         mo = re.match(r"fiveeq::small_octet_kernel<(double|float)>", k)                             # 4 + 1 + 1: one member per octet of lanes
         comp = m is not None and m.group(1) == "fused" and m.group(6).replace(" ", "") == ",false,false,true"      # the compensated fp32 form
         if mo:
