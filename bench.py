@@ -40,8 +40,9 @@ index, name, PCI bus id, uuid), `timing.per_rank_ms_per_step`, `timing.per_rank_
 plane, so they survive an RCCL failure — and, inside the protected summary section, `summary.rccl_world_size` /
 `summary.backend_seen` as the data group itself reports them after its first collective, and the bytes every rank sent the root.  The barriers around the clocked region and the MAX of the
 clocked times go over a gloo control group (host scalars); the end-of-run summary exchange — the only collective that moves
-ensemble data — goes over RCCL, LAST, with the line already complete and a watchdog thread beside it: a failed or hung
-exchange costs the line its `summary` (-> {"error": ...}, non-zero exit), never its measurement.  Every rank's host thread is bound
+ensemble data — goes over RCCL, LAST, with the line already complete and a watchdog thread beside it: an RCCL exchange that FAILS
+(first contact across xGMI refusing to come up) is repeated over the gloo control plane — the line then carries the summary AND
+`summary.rccl_error`, exit 0; one that HANGS costs the line its `summary` (-> {"error": ...}, non-zero exit), never its measurement.  Every rank's host thread is bound
 to the CPUs next to its GPU (fiveeqscm_amd/hostbind.py: sysfs, os.sched_setaffinity, BEFORE the first GPU call; no wrapper, no
 re-exec) and says so in `config.devices[].cpus` / `.cpu_binding`; `.side_streams` says whether the side stream of the two-launch
 per-step form passed its concurrency probe.
@@ -407,41 +408,65 @@ def main():
         print(f"rank {rank}: summary exchange timed out", file=sys.stderr, flush=True)
         os._exit(4)
 
-    summary_error = None
+    summary_error, summary_obj = None, None
     if rows is not None:
         watchdog = None
         if dist is not None:
             watchdog = threading.Timer(a.summary_watchdog_s, on_timeout)
             watchdog.daemon = True
             watchdog.start()
+
+        def exchange(group):
+            """The summary exchange over `group`, warm call timed: the `summary` object of the line (rank 0) or None."""
+            stats_ = {}
+            gather_summary(rows, percentiles=(5.0, 50.0, 95.0), group=group)            # warm: communicator + library set-up
+            ctl.sync_all()
+            ts = time.perf_counter()
+            summ = gather_summary(rows, percentiles=(5.0, 50.0, 95.0), group=group, stats=stats_)
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - ts) * 1e3
+            seen = {"rccl_world_size": None, "backend_seen": None}
+            if dist is not None:               # as the group itself reports them, after its first collectives have run
+                seen = {"rccl_world_size": dist.get_world_size(group), "backend_seen": dist.get_backend(group)}
+            if rank != 0:
+                return None
+            return {"years": years, "gather_ms": ms, "gather_ms_is": "second (warm) call", **seen,
+                    "bytes_to_root": stats_.get("bytes_to_root"), "bytes_to_root_per_rank": stats_.get("bytes_to_root_per_rank"),
+                    "allreduce_bytes": stats_.get("allreduce_bytes"), "T_mean": [float(x) for x in summ["mean"]],
+                    "T_p05_p50_p95": [[float(v) for v in row] for row in summ["percentiles"]]}
+
         try:
             if os.environ.get("FIVEEQ_BENCH_HANG_SUMMARY") == str(rank):     # test hook: this rank never enters the exchange
                 time.sleep(10 * a.summary_watchdog_s + 60)
-            summary_stats, data_group = {}, None
+            data_group = None
             if dist is not None:               # data plane: RCCL ("nccl" on ROCm); its communicator comes up with the first collective
                 data_group = dist.new_group(backend="nccl", timeout=ctl.timeout) if backend == "nccl" else dist.group.WORLD
-            gather_summary(rows, percentiles=(5.0, 50.0, 95.0), group=data_group)       # warm: communicator + library set-up
-            ctl.sync_all()
-            ts = time.perf_counter()
-            summ = gather_summary(rows, percentiles=(5.0, 50.0, 95.0), group=data_group, stats=summary_stats)
-            torch.cuda.synchronize(dev)
-            summary_ms = (time.perf_counter() - ts) * 1e3
-            if watchdog is not None:
-                watchdog.cancel()
-            seen = {"rccl_world_size": None, "backend_seen": None}
-            if dist is not None:               # as the DATA group reports them, after its first collectives have run
-                seen = {"rccl_world_size": dist.get_world_size(data_group), "backend_seen": dist.get_backend(data_group)}
-            if rank == 0:
-                emit({"years": years, "gather_ms": summary_ms, "gather_ms_is": "second (warm) call", **seen,
-                      "bytes_to_root": summary_stats.get("bytes_to_root"),
-                      "bytes_to_root_per_rank": summary_stats.get("bytes_to_root_per_rank"),
-                      "allreduce_bytes": summary_stats.get("allreduce_bytes"),
-                      "T_mean": [float(x) for x in summ["mean"]],
-                      "T_p05_p50_p95": [[float(v) for v in row] for row in summ["percentiles"]]})
+            summary_obj = exchange(data_group)
         except Exception as exc:  # noqa: BLE001 - the measurement is complete: report the failure in the line, do not lose it
             summary_error = f"{type(exc).__name__}: {exc}"
-            if watchdog is not None:
-                watchdog.cancel()
+        if dist is not None and backend == "nccl":
+            # Did RCCL fail on first contact?  Every rank says so over the CONTROL plane (a rank whose peers hang inside RCCL waits
+            # here until the watchdog ends the job, as before).  If any rank failed — the usual first-contact failures are
+            # symmetric: every rank's communicator refuses to come up — ALL ranks run the exchange once more over the control
+            # plane's gloo group (rows through host memory): the line then carries a complete summary AND the RCCL error, and the
+            # job exits 0; the multi-GPU measurement is not held hostage by the one collective that is not part of it.
+            try:
+                errs = ctl.gather_over_ranks(summary_error)
+                if any(e is not None for e in errs):
+                    first = next(e for e in errs if e is not None)
+                    print(f"rank {rank}: RCCL summary exchange failed ({first[:200]}): repeating it over gloo", file=sys.stderr, flush=True)
+                    summary_obj = exchange(dist.group.WORLD)
+                    if summary_obj is not None:
+                        summary_obj["rccl_error"] = first
+                        summary_obj["rccl_errors_per_rank"] = errs
+                        summary_obj["fallback"] = "the exchange was repeated over the gloo control plane after RCCL failed"
+                    summary_error = None
+            except Exception as exc:  # noqa: BLE001
+                summary_error = f"{summary_error}; gloo fallback: {type(exc).__name__}: {exc}"
+        if watchdog is not None:
+            watchdog.cancel()
+        if summary_error is None and rank == 0:
+            emit(summary_obj)
     else:
         emit(None)
     if summary_error is not None:

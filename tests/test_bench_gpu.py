@@ -218,21 +218,25 @@ def test_a_hung_summary_exchange_cannot_lose_the_measured_line():
     assert "timeout" in d["summary"]["error"] and d["value"] > 0 and d["n_gpus"] == 2 and d["roofline"]["frac"] > 0
 
 
-def test_an_rccl_failure_on_first_contact_costs_the_summary_not_the_measurement():
+def test_an_rccl_failure_on_first_contact_is_reported_and_the_exchange_repeated_over_gloo():
     """Two ranks over RCCL on the ONE GPU of the test box: RCCL refuses two ranks on one device when its communicator comes up
-    — a real first-contact failure.  That happens in the summary section, after the measurement: rank 0 must still print the
-    complete line, with summary.error, and the job must exit non-zero."""
+    — a real first-contact failure, on every rank alike.  That happens in the summary section, after the measurement: every rank
+    reports it over the control plane, ALL repeat the exchange over gloo, and rank 0 prints the complete line — the summary of the
+    whole ensemble, the RCCL error beside it — and the job exits 0 (round 6: a multi-GPU measurement is not held hostage by the
+    one collective that is not part of it; a HUNG exchange still ends in the watchdog, the test above)."""
     import torch
     if torch.cuda.device_count() != 1:
         pytest.skip("needs a box where two ranks must share one GPU")
-    out = _plain(2, *_SMALL, "--summary-watchdog-s", "25", env={"FIVEEQ_BENCH_BACKEND": "nccl"}, timeout=400)
-    assert out.returncode != 0
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-1500:] + out.stderr[-3000:]
-    d = json.loads(lines[0])
-    assert "error" in d["summary"] and d["value"] > 0 and d["n_gpus"] == 2 and d["config"]["collective_backend"] == "rccl"
+    out = _plain(2, *_SMALL, "--summary-watchdog-s", "60", env={"FIVEEQ_BENCH_BACKEND": "nccl"}, timeout=400)
+    d = _one_line(out)
+    sm = d["summary"]
+    assert "error" not in sm and sm["rccl_error"] and len(sm["rccl_errors_per_rank"]) == 2 and all(sm["rccl_errors_per_rank"])
+    assert sm["backend_seen"] == "gloo" and sm["rccl_world_size"] == 2 and "gloo" in sm["fallback"]
+    assert d["value"] > 0 and d["n_gpus"] == 2 and d["config"]["collective_backend"] == "rccl"
     assert d["config"]["control_plane"].startswith("gloo") and d["timing"]["host_share"] > 0
-    print("RCCL first-contact failure reported as:", d["summary"]["error"][:200])
+    ref = _one_line(_plain(2, *_SMALL))                                      # the same job with gloo as its data plane from the start
+    _summaries_agree(sm, ref["summary"], rel=0.0)
+    print("RCCL first-contact failure reported as:", sm["rccl_error"][:200])
 
 
 def test_a_host_bound_multi_rank_run_falls_back_to_graph_replay():
